@@ -1,0 +1,275 @@
+"""Generate the golden fixtures in this directory from the REFERENCE'S OWN code.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes (small .npz files) are committed, this script is committed, no
+reference source is copied.  Usage:  python tests/golden/make_golden.py
+
+How: the reference imports Megatron / MindSpeed / ModelLink / torch_npu, none
+of which is installed.  A ``sys.meta_path`` finder fabricates empty stand-in
+modules for those roots (every attribute is an inert stub), the reference
+modules are then imported unmodified, and the few ambient hooks the exercised
+functions read (``get_args``, ``mpu`` ranks, the global memory buffer, the RNG
+tracker, the scale-mask-softmax of Megatron) are set on the imported module
+objects.  Functions that hard-code ``device='cuda'`` are run with
+``torch.arange``/``torch.tensor`` wrapped to drop the device argument.
+
+Fixtures written:
+  eager_attention.npz  reference eager attention wrapper
+                       (dot_product_attention.py:148-288) on seeded inputs
+  indexing.npz         index_of_a_in_b, zig-zag CP slicing, src/tgt image
+                       index remap (training/utils.py), collate_fn
+                       (legacy/data/data_samplers.py), pixel_shuffle
+                       (pretrain_lcvlm.py), get_pos_emb_on_this_cp_rank
+                       (rotary_pos_embedding.py)
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+STUB_ROOTS = ("megatron", "mindspeed", "torch_npu", "modellink", "apex", "amp_C", "cognitron_vl")
+
+
+class _StubMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Stub
+
+
+class _Stub(metaclass=_StubMeta):
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Stub()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Stub()
+
+
+class _StubModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Stub
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_shim():
+    sys.meta_path.insert(0, _Finder())
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+@contextlib.contextmanager
+def no_cuda_device():
+    """Drop device='cuda' from the tensor factories the reference calls."""
+    saved = {}
+
+    def wrap(fn):
+        def inner(*a, **k):
+            if "device" in k and str(k["device"]).startswith("cuda"):
+                k = dict(k)
+                k.pop("device")
+            return fn(*a, **k)
+        return inner
+
+    for name in ("arange", "tensor", "ones", "zeros", "empty"):
+        saved[name] = getattr(torch, name)
+        setattr(torch, name, wrap(saved[name]))
+    try:
+        yield
+    finally:
+        for name, fn in saved.items():
+            setattr(torch, name, fn)
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+# --------------------------------------------------------------------------
+def gen_eager_attention():
+    dpa = importlib.import_module("lcvlm_modellink.core.transformer.dot_product_attention")
+
+    def smsoftmax(scores, mask):
+        # Megatron FusedScaleMaskSoftmax (core_r0.6.0), unfused path with
+        # attention_softmax_in_fp32 and scale=None: mask fill -10000, fp32
+        # softmax, cast back.  Not part of the reference tree; restated.
+        x = scores.float()
+        if mask is not None:
+            x = x.masked_fill(mask, -10000.0)
+        return torch.softmax(x, dim=-1).to(scores.dtype)
+
+    dpa.get_args = lambda: ns(use_flash_attn=False)
+    dpa.parallel_state = ns(get_global_memory_buffer=lambda: ns(
+        get_tensor=lambda shape, dtype, name: torch.empty(shape, dtype=dtype)))
+    dpa.tensor_parallel = ns(get_cuda_rng_tracker=lambda: ns(fork=contextlib.nullcontext))
+    wrapper = dpa.dot_product_attention_forward_wrapper(lambda *a, **k: None)
+
+    out = {}
+    cases = [
+        # name, sq, b, np, ng, hn
+        ("gqa_small", 48, 1, 4, 2, 16),
+        ("gqa_b2", 33, 2, 10, 2, 32),
+        ("mha_d64", 65, 1, 4, 4, 64),
+        ("qwen_ratio", 96, 1, 10, 2, 128),
+    ]
+    g = torch.Generator().manual_seed(20241223)
+    for name, sq, b, np_, ng, hn in cases:
+        q = torch.randn(sq, b, np_, hn, generator=g).to(torch.bfloat16).float()
+        k = torch.randn(sq, b, ng, hn, generator=g).to(torch.bfloat16).float()
+        v = torch.randn(sq, b, ng, hn, generator=g).to(torch.bfloat16).float()
+        mask = torch.triu(torch.ones(sq, sq, dtype=torch.bool), 1)[None, None]
+        self = ns(num_attention_heads_per_partition=np_, num_query_groups_per_partition=ng,
+                  alibi=None, norm_factor=float(hn) ** 0.5, attn_logit_softcapping=None,
+                  square_alibi_mask=False, scale_mask_softmax=smsoftmax,
+                  config=ns(sequence_parallel=True), attention_dropout=lambda x: x,
+                  hidden_size_per_partition=np_ * hn)
+        o = wrapper(self, q, k, v, mask, None, None)
+        out[f"{name}.q"] = q.numpy()
+        out[f"{name}.k"] = k.numpy()
+        out[f"{name}.v"] = v.numpy()
+        out[f"{name}.out"] = o.numpy()
+        # non-causal (ViT branch semantics: no mask at all)
+        o2 = wrapper(self, q, k, v, torch.zeros(1, 1, sq, sq, dtype=torch.bool), None, None)
+        out[f"{name}.out_nomask"] = o2.numpy()
+    np.savez_compressed(os.path.join(HERE, "eager_attention.npz"), **out)
+    print("eager_attention.npz:", len(out), "arrays")
+
+
+def gen_indexing():
+    out = {}
+    tu = importlib.import_module("lcvlm_modellink.training.utils")
+
+    # index_of_a_in_b ------------------------------------------------------
+    rng = np.random.default_rng(7)
+    b = rng.permutation(200)[:64].astype(np.int64)
+    a = rng.permutation(b)[:40]
+    out["ioab.a"], out["ioab.b"] = a, b
+    out["ioab.out"] = tu.index_of_a_in_b(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+
+    # zig-zag slicing + image remap for several (S, CP) --------------------
+    for S, cp, n_img, n_tok in [(64, 2, 3, 4), (256, 4, 5, 16), (1024, 8, 3, 256)]:
+        tokens = torch.arange(2 * S, dtype=torch.int64).view(2, S) * 3 + 1
+        pos = torch.arange(S, dtype=torch.int64).repeat(2, 1)
+        # images: disjoint runs of n_tok consecutive positions, batch row alternating
+        starts = np.sort(rng.choice(np.arange(0, S - n_tok, n_tok + 1), size=n_img, replace=False))
+        ind_s = torch.from_numpy(np.stack([np.arange(s, s + n_tok) for s in starts]).astype(np.int64))
+        ind_b = torch.from_numpy((np.arange(n_img) % 2)[:, None].repeat(n_tok, 1).astype(np.int64))
+        ext = torch.stack([ind_b, ind_s])
+        images = torch.arange(n_img * 6, dtype=torch.float32).view(n_img, 6)
+        tag = f"zz.S{S}.cp{cp}"
+        out[f"{tag}.tokens"] = tokens.numpy()
+        out[f"{tag}.external_indices"] = ext.numpy()
+        out[f"{tag}.images"] = images.numpy()
+        for r in range(cp):
+            tu.get_args = lambda: ns(seq_length=S, vision_context_parallel=False)
+            tu.mpu = ns(get_context_parallel_rank=lambda r=r: r, get_context_parallel_world_size=lambda: cp)
+            batch = {"tokens": tokens.clone(), "position_ids": pos.clone(), "attention_mask": None,
+                     "external_images": images.clone(), "external_indices": ext.clone()}
+            with no_cuda_device():
+                res = tu._get_batch_on_this_cp_rank_in_megatron_cp(batch)
+            out[f"{tag}.r{r}.tokens"] = res["tokens"].numpy()
+            out[f"{tag}.r{r}.position_ids"] = res["position_ids"].numpy()
+            out[f"{tag}.r{r}.images"] = res["external_images"].numpy()
+            if "external_src_indices" in res:
+                out[f"{tag}.r{r}.src"] = res["external_src_indices"].numpy()
+                out[f"{tag}.r{r}.tgt"] = res["external_tgt_indices"].numpy()
+
+    # collate_fn -----------------------------------------------------------
+    ds = importlib.import_module("lcvlm_modellink.legacy.data.data_samplers")
+    S = 32
+    rows = []
+    asl = [[5, 20, 32], [11, 12, 32], [7, 30, 32]]   # default_collate stacks them: equal counts
+    imgs = [np.stack([np.zeros((2, 4), np.int64), np.array([[1, 2, 3, 4], [10, 11, 12, 13]])]), None,
+            np.stack([np.zeros((1, 4), np.int64), np.array([[20, 21, 22, 23]])])]
+    for i in range(3):
+        d = {"tokens": torch.arange(S) + 100 * i, "actual_seq_len": torch.tensor(asl[i], dtype=torch.int64)}
+        if imgs[i] is not None:
+            d["image_indices"] = torch.from_numpy(imgs[i].copy())
+            d["images"] = torch.full((imgs[i].shape[1], 3), float(i))
+        rows.append(d)
+    col = ds.collate_fn(rows)
+    out["collate.in_actual0"] = np.asarray(asl[0])
+    out["collate.in_actual1"] = np.asarray(asl[1])
+    out["collate.in_actual2"] = np.asarray(asl[2])
+    out["collate.in_img0"] = imgs[0]
+    out["collate.in_img2"] = imgs[2]
+    out["collate.actual_seq_len"] = col["actual_seq_len"].numpy()
+    out["collate.image_indices"] = col["image_indices"].numpy()
+    out["collate.images"] = col["images"].numpy()
+
+    # pixel_shuffle: take the method from the class body without building the model
+    pl = importlib.import_module("lcvlm_modellink.pretrain_lcvlm")
+    ps = pl.MegatronVisionModel.pixel_shuffle
+    x = torch.arange(2 * 8 * 8 * 16, dtype=torch.float32).view(2, 8, 8, 16)
+    out["ps.small.in"] = x.numpy()
+    out["ps.small.out"] = ps(None, x, scale_factor=0.5).numpy()
+    # full-size permutation as an index map: value = flat source index (int32 exact in fp32? no -> use int64)
+    xi = torch.arange(32 * 32 * 1024, dtype=torch.int64).view(1, 32, 32, 1024)
+    out["ps.full.index_map"] = ps(None, xi, scale_factor=0.5).numpy().astype(np.int32)
+
+    # RoPE zig-zag slice ------------------------------------------------------
+    rope = importlib.import_module("lcvlm_modellink.core.models.common.embeddings.rotary_pos_embedding")
+    emb = torch.arange(64 * 8, dtype=torch.float32).view(64, 1, 1, 8)
+    real_tensor = torch.tensor
+
+    class _T(torch.Tensor):
+        pass
+
+    def tensor_nopin(*a, **k):
+        k.pop("pin_memory", None)
+        k.pop("device", None)
+        t = real_tensor(*a, **k)
+        return t
+    for cp in (2, 4):
+        for r in range(cp):
+            rope.parallel_state = ns(get_context_parallel_world_size=lambda cp=cp: cp,
+                                     get_context_parallel_rank=lambda r=r: r)
+            torch.tensor = tensor_nopin
+            torch.Tensor.cuda_saved = getattr(torch.Tensor, "cuda")
+            torch.Tensor.cuda = lambda self, *a, **k: self
+            try:
+                o = rope.get_pos_emb_on_this_cp_rank(emb, 0)
+            finally:
+                torch.tensor = real_tensor
+                torch.Tensor.cuda = torch.Tensor.cuda_saved
+            out[f"rope.cp{cp}.r{r}"] = o.numpy()
+    out["rope.in"] = emb.numpy()
+
+    np.savez_compressed(os.path.join(HERE, "indexing.npz"), **out)
+    print("indexing.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    install_shim()
+    gen_eager_attention()
+    gen_indexing()

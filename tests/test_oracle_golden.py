@@ -1,0 +1,126 @@
+"""The CPU oracle against the fixtures produced by the reference's own code
+(tests/golden/make_golden.py).  No GPU needed."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import attention_ref as A
+from oracle import indexing_ref as I
+
+CASES = [("gqa_small", 48, 1, 4, 2, 16), ("gqa_b2", 33, 2, 10, 2, 32),
+         ("mha_d64", 65, 1, 4, 4, 64), ("qwen_ratio", 96, 1, 10, 2, 128)]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_eager_restatement_matches_reference_wrapper(golden_dir):
+    g = _load(golden_dir, "eager_attention.npz")
+    for name, sq, b, np_, ng, hn in CASES:
+        q, k, v = (torch.from_numpy(g[f"{name}.{x}"]) for x in "qkv")
+        out = A.eager_attention(q, k, v, A.causal_mask(sq, sq), float(hn) ** 0.5)
+        assert torch.equal(out, torch.from_numpy(g[f"{name}.out"])), name
+        out2 = A.eager_attention(q, k, v, None, float(hn) ** 0.5)
+        np.testing.assert_allclose(out2.numpy(), g[f"{name}.out_nomask"], rtol=0, atol=1e-6)
+
+
+def test_fp64_attention_matches_reference_eager(golden_dir):
+    """The float64 varlen/dense restatement agrees with the reference's eager
+    fp32 output to fp32 rounding: same softmax, GQA mapping, scale, layout."""
+    g = _load(golden_dir, "eager_attention.npz")
+    for name, sq, b, np_, ng, hn in CASES:
+        q, k, v = (g[f"{name}.{x}"] for x in "qkv")
+        ref = g[f"{name}.out"].reshape(sq, b, np_, hn)
+        ref_nm = g[f"{name}.out_nomask"].reshape(sq, b, np_, hn)
+        for bi in range(b):
+            o, lse = A.varlen_attention(q[:, bi], k[:, bi], v[:, bi], [0, sq], A.default_scale(hn))
+            np.testing.assert_allclose(o, ref[:, bi], rtol=0, atol=2e-5)
+            o, _ = A.varlen_attention(q[:, bi], k[:, bi], v[:, bi], [0, sq], A.default_scale(hn), causal=False)
+            np.testing.assert_allclose(o, ref_nm[:, bi], rtol=0, atol=2e-5)
+            assert np.isfinite(lse).all()
+
+
+def test_fp64_grad_matches_autograd_of_eager():
+    torch.manual_seed(3)
+    T, Hq, Hkv, D = 40, 4, 2, 16
+    cu = [0, 7, 25, 40]
+    q = torch.randn(T, Hq, D, dtype=torch.float64, requires_grad=True)
+    k = torch.randn(T, Hkv, D, dtype=torch.float64, requires_grad=True)
+    v = torch.randn(T, Hkv, D, dtype=torch.float64, requires_grad=True)
+    do = torch.randn(T, Hq, D, dtype=torch.float64)
+    # block-diagonal causal mask = what packed varlen attention means
+    seg = torch.zeros(T, dtype=torch.long)
+    for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+        seg[a:b] = i
+    mask = (seg[:, None] != seg[None, :]) | torch.triu(torch.ones(T, T, dtype=torch.bool), 1)
+    out = A.eager_attention(q[:, None], k[:, None], v[:, None], mask[None, None], D ** 0.5)
+    out.backward(do.reshape(T, 1, Hq * D))
+    dq, dk, dv = A.varlen_attention_grad(q, k, v, do, cu, A.default_scale(D))
+    o64, _ = A.varlen_attention(q, k, v, cu, A.default_scale(D))
+    # the eager path's softmax runs in fp32 (scale_mask_softmax), hence 1e-5 not 1e-12
+    np.testing.assert_allclose(o64.reshape(T, 1, -1), out.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(dq, q.grad.numpy(), atol=1e-5)
+    np.testing.assert_allclose(dk, k.grad.numpy(), atol=1e-5)
+    np.testing.assert_allclose(dv, v.grad.numpy(), atol=1e-5)
+
+
+def test_ring_simulation_equals_full_causal():
+    rng = np.random.default_rng(0)
+    for cp in (1, 2, 4):
+        S, Hq, Hkv, D = 64, 4, 2, 8
+        q, k, v = rng.standard_normal((S, Hq, D)), rng.standard_normal((S, Hkv, D)), rng.standard_normal((S, Hkv, D))
+        full, lse = A.varlen_attention(q, k, v, [0, S], 0.3)
+        res = A.ring_attention_simulated(q, k, v, 0.3, cp)
+        outs = [r[0][None] for r in res]
+        got = I.unzigzag_concat(outs, cp, seq_dim=1)[0]
+        np.testing.assert_allclose(got, full, atol=1e-12)
+        lses = [r[1] for r in res]
+        np.testing.assert_allclose(I.unzigzag_concat(lses, cp, seq_dim=1), lse, atol=1e-12)
+
+
+def test_indexing_oracle_matches_reference(golden_dir):
+    g = _load(golden_dir, "indexing.npz")
+    np.testing.assert_array_equal(I.index_of_a_in_b(g["ioab.a"], g["ioab.b"]), g["ioab.out"])
+    for S, cp in [(64, 2), (256, 4), (1024, 8)]:
+        tag = f"zz.S{S}.cp{cp}"
+        tokens, ext, images = g[f"{tag}.tokens"], g[f"{tag}.external_indices"], g[f"{tag}.images"]
+        per_rank = []
+        for r in range(cp):
+            got = I.zigzag_slice(tokens, cp, r, 1)
+            np.testing.assert_array_equal(got, g[f"{tag}.r{r}.tokens"])
+            per_rank.append(got)
+            sel, src, tgt = I.cp_image_remap(ext, S, cp, r)
+            if sel is None:
+                assert f"{tag}.r{r}.src" not in g.files
+                np.testing.assert_array_equal(images, g[f"{tag}.r{r}.images"])
+            else:
+                np.testing.assert_array_equal(images[sel], g[f"{tag}.r{r}.images"])
+                np.testing.assert_array_equal(src, g[f"{tag}.r{r}.src"])
+                np.testing.assert_array_equal(tgt, g[f"{tag}.r{r}.tgt"])
+        np.testing.assert_array_equal(I.unzigzag_concat(per_rank, cp, 1), tokens)
+    np.testing.assert_array_equal(
+        I.collate_actual_seq_len([g["collate.in_actual0"], g["collate.in_actual1"], g["collate.in_actual2"]]),
+        g["collate.actual_seq_len"])
+    np.testing.assert_array_equal(
+        I.collate_image_indices([g["collate.in_img0"], None, g["collate.in_img2"]]), g["collate.image_indices"])
+    np.testing.assert_array_equal(I.pixel_shuffle(g["ps.small.in"]), g["ps.small.out"])
+    full = np.arange(32 * 32 * 1024, dtype=np.int32).reshape(1, 32, 32, 1024)
+    np.testing.assert_array_equal(I.pixel_shuffle(full), g["ps.full.index_map"])
+    for cp in (2, 4):
+        for r in range(cp):
+            np.testing.assert_array_equal(I.zigzag_slice(g["rope.in"], cp, r, 0), g[f"rope.cp{cp}.r{r}"])
+
+
+def test_pack_samples_semantics():
+    pos0, n0 = I.image_token_layout(3, 2, 4)
+    assert n0 == 3 + 2 * 6 and pos0.tolist() == [[4, 5, 6, 7], [10, 11, 12, 13]]
+    actual, pids, img = I.pack_samples([15, 9], [pos0, None], 32)
+    assert actual.tolist() == [15, 32]
+    assert pids.tolist() == list(range(15)) + list(range(9)) + [8] * 8
+    assert img.shape == (2, 2, 4) and img[1].tolist() == pos0.tolist()
+    actual, pids, img = I.pack_samples([10, 15], [None, pos0], 20)
+    assert actual.tolist() == [10, 20] and len(pids) == 20
+    assert img[1].tolist() == (pos0 + 10).tolist()
+    assert I.cu_seqlens_from_actual(actual).tolist() == [0, 10, 20]
