@@ -1,0 +1,154 @@
+/* lvattn.h — C ABI of the MI355X (gfx950) attention hot path for Long-VITA.
+ *
+ * The reference has no FFI of its own: its "operator API" on this path is a set
+ * of Python call sites into kernels that live in torch_npu / MindSpeed.  Every
+ * entry point below names the reference call site it stands in for.  All
+ * pointers are raw device pointers unless the name ends in _host; sizes and
+ * strides are in ELEMENTS (bf16) unless stated; `stream` is a hipStream_t passed
+ * as void*.  Return value: 0 on success, a negative LV_E* code otherwise, with a
+ * message retrievable through lvattn_last_error().  No entry point allocates,
+ * frees or synchronises: callers pass every buffer (graph-capture friendly).
+ *
+ * Block descriptors
+ * -----------------
+ * The attention kernels are driven by a device array of 8-int32 descriptors, one
+ * per (query-block x key-range) work item, so that the same kernel serves packed
+ * variable-length causal attention, dense ViT attention and the sub-blocks of the
+ * zig-zag ring:
+ *   [0] q_row0   first query row of the block (row index into the q / out tensors)
+ *   [1] q_rows   valid query rows in the block (1 .. LV_FWD_BLOCK_M)
+ *   [2] k_row0   first key row the block may attend to (row index into k / v)
+ *   [3] k_len    number of key rows from k_row0 the block may attend to
+ *   [4] shift    causal rule: key k_row0+j visible to query q_row0+i iff j <= i + shift
+ *                (ignored by the non-causal kernels)
+ *   [5..7] reserved, must be 0
+ * The backward kernels use the transposed descriptor (one per key block):
+ *   [0] k_row0  [1] k_rows (1 .. LV_BWD_BLOCK_N)  [2] q_row0  [3] q_len
+ *   [4] shift   key k_row0+j visible to query q_row0+i iff j <= i + shift - ... (see lv_build_bwd_blocks)
+ */
+#ifndef LVATTN_H
+#define LVATTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LV_OK 0
+#define LV_EINVAL (-1)   /* bad argument (shape, stride, alignment, null pointer) */
+#define LV_ELAUNCH (-2)  /* HIP reported a launch error */
+#define LV_ESIZE (-3)    /* output buffer too small */
+
+#define LV_FWD_BLOCK_M 256 /* query rows per forward work item  */
+#define LV_BWD_BLOCK_N 128 /* key rows per backward work item   */
+#define LV_DESC_INTS 8
+
+/* Library identification / diagnostics. */
+int lvattn_abi_version(void);
+const char* lvattn_last_error(void);
+
+/* ---- host-side block builders (pure CPU, no HIP calls) -------------------
+ * cu_seqlens_host = [0] + the reference's `actual_seq_len` cumulative end offsets
+ * (lcvlm_modellink/core/transformer/dot_product_attention.py:333,363-364;
+ * produced by cognitron_vl/data/dataset_qwen2.py:166,209-219 and
+ * lcvlm_modellink/legacy/data/data_samplers.py:45-48).
+ * Writes up to max_blocks descriptors ordered heaviest-first; returns the count,
+ * or LV_ESIZE if max_blocks is too small (needed: sum ceil(L_i / block)). */
+int lv_build_fwd_blocks(const int32_t* cu_seqlens_host, int n_seg, int causal,
+                        int32_t* desc_host, int max_blocks);
+int lv_build_bwd_blocks(const int32_t* cu_seqlens_host, int n_seg, int causal,
+                        int32_t* desc_host, int max_blocks);
+/* One rectangular (q rows x k rows) region, e.g. a ring step: q_row0..+q_len
+ * against k_row0..+k_len, with `shift` as above when causal. */
+int lv_build_fwd_blocks_rect(int q_row0, int q_len, int k_row0, int k_len, int causal, int shift,
+                             int32_t* desc_host, int max_blocks);
+int lv_build_bwd_blocks_rect(int q_row0, int q_len, int k_row0, int k_len, int causal, int shift,
+                             int32_t* desc_host, int max_blocks);
+
+/* ---- attention forward ------------------------------------------------------
+ * Replaces torch_npu.npu_fusion_attention(...)[0] at
+ *   dot_product_attention.py:352-365 (TND, packed varlen causal, sparse_mode=2),
+ *   dot_product_attention.py:314-325 (SBH, ViT, no mask; causal=0),
+ *   dot_product_attention.py:454-467 (generic causal),
+ * and the per-step block attention inside MindSpeed's ringattn_context_parallel
+ * (call site dot_product_attention.py:70-71).
+ * q [rows, hq, d], k/v [rows, hkv, d], out [rows, hq, d] bf16 with explicit row and
+ * head strides (last dim contiguous, 16-byte aligned rows); lse fp32 [hq, lse_stride]
+ * natural-log log-sum-exp of the scaled scores (-inf for rows with no visible key,
+ * whose output is 0).  d in {64, 128}; hq % hkv == 0.
+ * q_rows_total / k_rows_total bound the row indices any descriptor may touch. */
+int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+               const int32_t* desc_dev, int n_blocks,
+               int q_rows_total, int k_rows_total, int hq, int hkv, int d,
+               int64_t q_row_stride, int64_t q_head_stride,
+               int64_t k_row_stride, int64_t k_head_stride,
+               int64_t v_row_stride, int64_t v_head_stride,
+               int64_t o_row_stride, int64_t o_head_stride,
+               int64_t lse_stride, float softmax_scale, int causal, void* stream);
+
+/* ---- attention backward -----------------------------------------------------
+ * Replaces the autograd of the calls above (npu_fusion_attention_grad, reached
+ * through torch autograd from dot_product_attention.py:352-365 / :314-325) and the
+ * per-step backward of the ring.
+ * Step 1: delta[h, row] = sum_d dout*out (fp32 [hq, lse_stride]).
+ * Step 2: per key block, accumulate dk/dv (bf16 out, or fp32 accumulate when
+ *         dkv_accum_f32 != 0: dk/dv are then fp32 buffers that are ADDED to) and
+ *         atomically add dq into the fp32 buffer dq_accum [rows, hq, d] (contiguous).
+ * Step 3: lvattn_cast_f32_bf16 turns dq_accum into bf16 with the caller's strides. */
+int lvattn_bwd_delta(const void* out, const void* dout, float* delta,
+                     int rows, int hq, int d,
+                     int64_t o_row_stride, int64_t o_head_stride,
+                     int64_t do_row_stride, int64_t do_head_stride,
+                     int64_t lse_stride, void* stream);
+int lvattn_bwd(const void* q, const void* k, const void* v, const void* dout,
+               const float* lse, const float* delta,
+               float* dq_accum, void* dk, void* dv,
+               const int32_t* desc_dev, int n_blocks,
+               int q_rows_total, int k_rows_total, int hq, int hkv, int d,
+               int64_t q_row_stride, int64_t q_head_stride,
+               int64_t k_row_stride, int64_t k_head_stride,
+               int64_t v_row_stride, int64_t v_head_stride,
+               int64_t do_row_stride, int64_t do_head_stride,
+               int64_t dk_row_stride, int64_t dk_head_stride,
+               int64_t dv_row_stride, int64_t dv_head_stride,
+               int64_t lse_stride, float softmax_scale, int causal, int dkv_accum_f32,
+               void* stream);
+int lvattn_cast_f32_bf16(const float* src, void* dst, int rows, int heads, int d,
+                         int64_t dst_row_stride, int64_t dst_head_stride, void* stream);
+
+/* ---- ring merge -------------------------------------------------------------
+ * The (out, softmax_max, softmax_sum) update MindSpeed's ringattn_context_parallel
+ * performs after each ring step, in log-sum-exp form:
+ *   lse' = log(exp(lse_acc) + exp(lse_blk));  out_acc = out_acc*exp(lse_acc-lse') + out_blk*exp(lse_blk-lse')
+ * out_acc fp32 [rows, hq, d] contiguous, lse_acc fp32 [hq, lse_stride], updated in
+ * place for rows [row0, row0+rows); out_blk bf16 [.., hq, d] / lse_blk indexed by the
+ * same absolute rows. */
+int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
+                 int row0, int rows, int hq, int d,
+                 int64_t blk_row_stride, int64_t blk_head_stride,
+                 int64_t lse_stride, void* stream);
+
+/* ---- token compression / indexing --------------------------------------------
+ * lv_pixel_shuffle: MegatronVisionModel.forward_once + pixel_shuffle(0.5)
+ * (lcvlm_modellink/pretrain_lcvlm.py:463-470, 546-556).  in [n, tokens_in, c] bf16
+ * where the first `skip` tokens of every image (the class token) are dropped and
+ * the remaining side*side tokens form a square grid; out [n, (side/2)^2, 4c]. */
+int lv_pixel_shuffle(const void* in, void* out, int n, int side, int c, int skip,
+                     int64_t in_image_stride, void* stream);
+/* lv_scatter_rows: LanguageModelEmbedding.forward visual-feature scatter
+ * (lcvlm_modellink/core/models/common/embeddings/language_model_embedding.py:123,131):
+ * dst[dst_index[i]] = src[src_index[i]] for i < n, rows of `width` bf16 elements
+ * (src_index may be NULL = identity).  Indices are flat row numbers (b*s + pos). */
+int lv_scatter_rows(const void* src, void* dst, const int64_t* src_index, const int64_t* dst_index,
+                    int64_t n, int width, int64_t src_rows, int64_t dst_rows, void* stream);
+/* lv_gather_rows: zig-zag context-parallel slicing of activations / RoPE tables
+ * (lcvlm_modellink/training/utils.py:351-362, rotary_pos_embedding.py:36-47,114-117):
+ * dst[i] = src[index[i]], rows of `row_bytes` bytes (multiple of 4). */
+int lv_gather_rows(const void* src, void* dst, const int64_t* index, int64_t n,
+                   int64_t row_bytes, int64_t src_rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVATTN_H */

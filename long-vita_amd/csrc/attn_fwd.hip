@@ -1,0 +1,250 @@
+// Flash-style attention forward for gfx950 (MI355X): bf16 MFMA, LDS-staged K/V,
+// online softmax with the query row on the lane, log-sum-exp output.
+//
+// One workgroup = 8 waves = one 256-row query block of one query head; wave w owns
+// rows 32w .. 32w+31.  Per 64-key K/V tile every wave issues 32 v_mfma_f32_32x32x16_bf16:
+//   S^T = K Q^T   (A = K rows from LDS, B = Q fragments kept in registers)
+//   O^T += V^T P^T (A = V read column-wise with ds_read_b64_tr_b16, B = P^T taken
+//                   straight from the S^T accumulator registers, cast to bf16)
+// so the query row stays on the lane (lane & 31) for S, P and O: the row maximum /
+// sum are 31 in-lane ops plus one exchange with lane ^ 32, and rescaling O is a
+// per-lane multiply.  K/V tiles are fetched global -> registers early and written to
+// the other LDS buffer after the tile's math (one barrier per tile).
+#include "internal.h"
+
+
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    if constexpr (D == 128) return lds_off128(row, chunk);
+    else return lds_off64(row, chunk);
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
+    constexpr int BN = 64;            // keys per tile
+    constexpr int KS = D / 16;        // k-steps of the QK^T product
+    constexpr int MT = D / 32;        // 32-wide d sub-tiles of the PV product
+    constexpr int ROWB = D * 2;       // bytes per K/V row
+    constexpr int TILEB = BN * ROWB;  // bytes per K or V tile
+    constexpr int CPR = D / 8;        // 16-byte chunks per row
+    constexpr int NLD = (BN * CPR) / 512;  // 16-byte loads per thread per tile (2 or 1)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [K buf0][K buf1][V buf0][V buf1]
+    char* const ldsK = smem;
+    char* const ldsV = smem + 2 * TILEB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // block id -> (kv head, descriptor, head within group); heads of a group are adjacent
+    // so that the workgroups in flight stream the same K/V tiles.
+    const int bid = blockIdx.x;
+    const int hg = bid % p.group;
+    const int rest = bid / p.group;
+    const int blk = rest % p.n_blocks;
+    const int kvh = rest / p.n_blocks;
+    const int head = kvh * p.group + hg;
+
+    const AttnDesc dsc = p.desc[blk];
+    const int q_row0 = dsc.a_row0, q_rows = dsc.a_rows;
+    const int k_row0 = dsc.b_row0, k_len = dsc.b_len;
+    const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
+
+    // ---- Q fragments: B operand of S^T = K Q^T : lane holds Q[row r][16ks + 8h .. +8]
+    const int qi = 32 * w + r;  // row inside the block
+    int q_row = q_row0 + (qi < q_rows ? qi : q_rows - 1);
+    const __bf16* qptr = p.q + (int64_t)q_row * p.q_rs + (int64_t)head * p.q_hs + 8 * h;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qptr + 16 * ks);
+
+    // visible keys (relative to k_row0) for this lane's row: j <= limit
+    int limit = qi + shift;
+    if (limit > k_len - 1 || qi >= q_rows) limit = k_len - 1;  // rows past q_rows are never stored
+    // keys this wave needs: up to row 32w+31
+    int wave_kmax = 32 * w + 32 + shift;
+    wave_kmax = wave_kmax < 0 ? 0 : (wave_kmax > k_len ? k_len : wave_kmax);
+    const int nkt = (k_len + BN - 1) / BN;
+    // waves whose 32 rows all lie past q_rows (short last block) only help with staging
+    const int my_nkt = (32 * w < q_rows) ? (wave_kmax + BN - 1) / BN : 0;
+
+    // ---- staging addresses (global -> regs -> LDS)
+    const __bf16* kbase = p.k + (int64_t)kvh * p.k_hs;
+    const __bf16* vbase = p.v + (int64_t)kvh * p.v_hs;
+    int st_row[NLD], st_lds[NLD], st_col[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        int c = tid + 512 * i;
+        st_row[i] = c / CPR;
+        int ch = c % CPR;
+        st_col[i] = ch * 8;
+        st_lds[i] = lds_off<D>(st_row[i], ch);
+    }
+    u32x4 kreg[NLD], vreg[NLD];
+    auto issue_loads = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int row = k_row0 + t * BN + st_row[i];
+            if (row > p.k_rows_total - 1) row = p.k_rows_total - 1;
+            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)row * p.k_rs + st_col[i]);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)row * p.v_rs + st_col[i]);
+        }
+    };
+    auto write_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            *reinterpret_cast<u32x4*>(ldsK + buf * TILEB + st_lds[i]) = kreg[i];
+            *reinterpret_cast<u32x4*>(ldsV + buf * TILEB + st_lds[i]) = vreg[i];
+        }
+    };
+
+    // ---- LDS read addresses
+    // K row read: row 32*st + r, chunk 2ks + h
+    int k_off[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) k_off[ks] = lds_off<D>(r, 2 * ks + h);
+    // V transposed read: 16-lane group g covers d columns 32mt + 16(g&1) + i, key rows
+    // 16s + 8jh + 4h + q4 ; lane 4*q4 + p4 supplies row q4, columns 4*p4 .. 4*p4+3.
+    const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gl = (lane >> 4) & 1;
+    int v_off[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            int row = 8 * jh + 4 * h + q4;
+            v_off[mt][jh] = lds_off<D>(row, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
+        }
+
+    f32x16 oacc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[mt][i] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float c = p.scale_log2e;
+
+    if (nkt > 0) {
+        issue_loads(0);
+        write_lds(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nkt; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < nkt);
+        if (more) issue_loads(t + 1);
+
+        if (t < my_nkt) {
+            const char* kb = ldsK + cur * TILEB;
+            const char* vb = ldsV + cur * TILEB;
+            // ---- S^T = K Q^T, two 32-key sub-tiles
+            f32x16 s[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[st][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + st * 32 * ROWB + k_off[ks]);
+                    s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
+                }
+            }
+            // ---- mask (only tiles that cross the causal diagonal or the key-range end)
+            const int kb0 = t * BN;
+            const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len);
+            if (need_mask) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        int j = kb0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        s[st][i] = (j > limit) ? -INFINITY : s[st][i];
+                    }
+            }
+            // ---- online softmax (row = lane & 31; the other half of the row is on lane ^ 32)
+            float mx = s[0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+            mx = pair32_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = fast_exp2((m_run - m_new) * c);
+            const float mc = m_new * c;
+            m_run = m_new;
+            float rs = 0.f;
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float pv = fast_exp2(__builtin_fmaf(s[st][i], c, -mc));
+                    rs += pv;
+                    pf[st][i >> 3][i & 7] = (__bf16)pv;
+                }
+            l_run = l_run * alpha + rs;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[mt][i] *= alpha;
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vrow = vb + (32 * st + 16 * s2) * ROWB;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, vrow + v_off[mt][0]));
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, vrow + v_off[mt][1]));
+                        bf16x8 vf;
+                        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st][s2], oacc[mt], 0, 0, 0);
+                    }
+                }
+        }
+        if (more) write_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, store O (row-per-lane, 8-byte pieces) and LSE
+    const float l_tot = pair32_sum(l_run);
+    const bool live = (qi < q_rows);
+    const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
+    if (live) {
+        __bf16* optr = p.o + (int64_t)(q_row0 + qi) * p.o_rs + (int64_t)head * p.o_hs;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (__bf16)(oacc[mt][4 * g4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(optr + 32 * mt + 8 * g4 + 4 * h) = ov;
+            }
+        if (h == 0) {
+            float lse = (l_tot > 0.f) ? (m_run * p.scale + __logf(l_tot)) : -INFINITY;
+            p.lse[(int64_t)head * p.lse_stride + q_row0 + qi] = lse;
+        }
+    }
+}
+
+int lv_launch_fwd(const FwdParams& p, int d, int causal, hipStream_t stream) {
+    dim3 grid((unsigned)((int64_t)p.n_blocks * p.hq));
+    dim3 block(512);
+    if (d == 128) {
+        size_t lds = 4 * 64 * 256;
+        if (causal) hipLaunchKernelGGL((lv_fwd_kernel<128, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_fwd_kernel<128, false>), grid, block, lds, stream, p);
+    } else {
+        size_t lds = 4 * 64 * 128;
+        if (causal) hipLaunchKernelGGL((lv_fwd_kernel<64, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_fwd_kernel<64, false>), grid, block, lds, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

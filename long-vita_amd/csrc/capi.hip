@@ -1,0 +1,372 @@
+// extern "C" entry points of liblvattn (declared in include/lvattn.h), the host-side
+// block builders, and the small bandwidth-bound kernels (ring merge, pixel shuffle,
+// row scatter / gather, fp32 -> bf16 cast).
+#include "../../include/lvattn.h"
+#include "internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int lvattn_abi_version(void) { return 1; }
+extern "C" const char* lvattn_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// host block builders
+// ---------------------------------------------------------------------------
+namespace {
+struct HostDesc {
+    int32_t v[LV_DESC_INTS];
+    int64_t work;
+};
+
+int emit(std::vector<HostDesc>& blocks, int32_t* out, int max_blocks) {
+    // heaviest first: the tail of the launch is then made of the cheapest work items
+    std::stable_sort(blocks.begin(), blocks.end(), [](const HostDesc& a, const HostDesc& b) { return a.work > b.work; });
+    if ((int)blocks.size() > max_blocks) return fail(LV_ESIZE, "need %d block descriptors, room for %d", (int)blocks.size(), max_blocks);
+    for (size_t i = 0; i < blocks.size(); ++i) memcpy(out + i * LV_DESC_INTS, blocks[i].v, sizeof(int32_t) * LV_DESC_INTS);
+    return (int)blocks.size();
+}
+
+// forward: query blocks of a rectangle q[q0, q0+ql) x k[k0, k0+kl)
+void fwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift) {
+    for (int m = 0; m < ql; m += LV_FWD_BLOCK_M) {
+        HostDesc d{};
+        int rows = std::min(LV_FWD_BLOCK_M, ql - m);
+        int klen = kl;
+        int sh = 0;
+        if (causal) {
+            sh = shift + m;  // key j visible to local row i iff j <= i + m + shift
+            int64_t vis = (int64_t)rows + sh;  // keys visible to the last row
+            klen = (int)std::max<int64_t>(0, std::min<int64_t>(kl, vis));
+        }
+        d.v[0] = q0 + m; d.v[1] = rows; d.v[2] = k0; d.v[3] = klen; d.v[4] = sh;
+        d.work = (int64_t)rows * klen;
+        blocks.push_back(d);
+    }
+}
+
+// backward: key blocks of the same rectangle; query rows that see at least one key of
+// the block start at i >= j0 - shift.
+void bwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift) {
+    for (int n = 0; n < kl; n += LV_BWD_BLOCK_N) {
+        HostDesc d{};
+        int rows = std::min(LV_BWD_BLOCK_N, kl - n);
+        int qstart = 0;
+        int sh = 0x3fffffff;
+        if (causal) {
+            // key j = n + jj visible to query i iff n + jj <= i + shift
+            qstart = std::max(0, n - shift);
+            qstart = std::min(qstart, ql);
+            qstart &= ~31;                 // keep 32-row slices aligned to the block start
+            sh = shift + qstart - n;       // jj <= ii + sh with ii relative to qstart
+        }
+        d.v[0] = k0 + n; d.v[1] = rows; d.v[2] = q0 + qstart; d.v[3] = ql - qstart; d.v[4] = sh;
+        d.work = (int64_t)rows * (ql - qstart);
+        blocks.push_back(d);
+    }
+}
+
+int check_cu(const int32_t* cu, int n_seg) {
+    if (!cu || n_seg < 0) return fail(LV_EINVAL, "cu_seqlens is null or n_seg < 0");
+    if (n_seg > 0 && cu[0] < 0) return fail(LV_EINVAL, "cu_seqlens[0] < 0");
+    for (int i = 0; i < n_seg; ++i)
+        if (cu[i + 1] < cu[i]) return fail(LV_EINVAL, "cu_seqlens not non-decreasing at %d", i);
+    return 0;
+}
+}  // namespace
+
+extern "C" int lv_build_fwd_blocks(const int32_t* cu, int n_seg, int causal, int32_t* out, int max_blocks) {
+    if (int e = check_cu(cu, n_seg)) return e;
+    std::vector<HostDesc> blocks;
+    for (int i = 0; i < n_seg; ++i) fwd_rect(blocks, cu[i], cu[i + 1] - cu[i], cu[i], cu[i + 1] - cu[i], causal, 0);
+    return emit(blocks, out, max_blocks);
+}
+extern "C" int lv_build_bwd_blocks(const int32_t* cu, int n_seg, int causal, int32_t* out, int max_blocks) {
+    if (int e = check_cu(cu, n_seg)) return e;
+    std::vector<HostDesc> blocks;
+    for (int i = 0; i < n_seg; ++i) bwd_rect(blocks, cu[i], cu[i + 1] - cu[i], cu[i], cu[i + 1] - cu[i], causal, 0);
+    return emit(blocks, out, max_blocks);
+}
+extern "C" int lv_build_fwd_blocks_rect(int q0, int ql, int k0, int kl, int causal, int shift, int32_t* out, int max_blocks) {
+    if (q0 < 0 || ql < 0 || k0 < 0 || kl < 0) return fail(LV_EINVAL, "negative rectangle");
+    std::vector<HostDesc> blocks;
+    fwd_rect(blocks, q0, ql, k0, kl, causal, shift);
+    return emit(blocks, out, max_blocks);
+}
+extern "C" int lv_build_bwd_blocks_rect(int q0, int ql, int k0, int kl, int causal, int shift, int32_t* out, int max_blocks) {
+    if (q0 < 0 || ql < 0 || k0 < 0 || kl < 0) return fail(LV_EINVAL, "negative rectangle");
+    std::vector<HostDesc> blocks;
+    bwd_rect(blocks, q0, ql, k0, kl, causal, shift);
+    return emit(blocks, out, max_blocks);
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+static int check_common(const void* q, const void* k, const void* v, int hq, int hkv, int d,
+                        int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs) {
+    if (!q || !k || !v) return fail(LV_EINVAL, "null q/k/v pointer");
+    if (d != 64 && d != 128) return fail(LV_EINVAL, "head dim %d not supported (64 or 128)", d);
+    if (hq <= 0 || hkv <= 0 || hq % hkv) return fail(LV_EINVAL, "hq=%d must be a positive multiple of hkv=%d", hq, hkv);
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return fail(LV_EINVAL, "q/k/v must be 16-byte aligned");
+    if ((q_rs | q_hs | k_rs | k_hs | v_rs | v_hs) & 7) return fail(LV_EINVAL, "row/head strides must be multiples of 8 elements");
+    return 0;
+}
+
+extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                          const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
+                          int hq, int hkv, int d,
+                          int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                          int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream) {
+    if (int e = check_common(q, k, v, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
+    if (!out || !lse || !desc_dev) return fail(LV_EINVAL, "null out/lse/desc pointer");
+    if (((uintptr_t)out & 7) || (o_rs & 3) || (o_hs & 3)) return fail(LV_EINVAL, "out must be 8-byte aligned with strides % 4 == 0");
+    if (n_blocks < 0 || q_rows_total <= 0 || k_rows_total <= 0) return fail(LV_EINVAL, "bad sizes");
+    if (lse_stride < q_rows_total) return fail(LV_EINVAL, "lse_stride %lld < q_rows_total %d", (long long)lse_stride, q_rows_total);
+    if (n_blocks == 0) return LV_OK;
+    if ((int64_t)n_blocks * hq > 0x7fffffffLL) return fail(LV_EINVAL, "grid too large");
+    FwdParams p;
+    p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.o = (__bf16*)out; p.lse = lse;
+    p.desc = (const AttnDesc*)desc_dev;
+    p.n_blocks = n_blocks; p.hq = hq; p.hkv = hkv; p.group = hq / hkv;
+    p.q_rows_total = q_rows_total; p.k_rows_total = k_rows_total;
+    p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
+    p.o_rs = o_rs; p.o_hs = o_hs; p.lse_stride = lse_stride;
+    p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+    if (lv_launch_fwd(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return LV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+extern "C" int lvattn_bwd_delta(const void* out, const void* dout, float* delta, int rows, int hq, int d,
+                                int64_t o_rs, int64_t o_hs, int64_t do_rs, int64_t do_hs, int64_t lse_stride, void* stream) {
+    if (!out || !dout || !delta) return fail(LV_EINVAL, "null pointer");
+    if (d != 64 && d != 128) return fail(LV_EINVAL, "head dim %d not supported (64 or 128)", d);
+    if (((uintptr_t)out | (uintptr_t)dout) & 15) return fail(LV_EINVAL, "out/dout must be 16-byte aligned");
+    if ((o_rs | o_hs | do_rs | do_hs) & 7) return fail(LV_EINVAL, "strides must be multiples of 8 elements");
+    if (rows < 0 || hq <= 0 || lse_stride < rows) return fail(LV_EINVAL, "bad sizes");
+    if (rows == 0) return LV_OK;
+    if (lv_launch_bwd_delta(out, dout, delta, rows, hq, d, o_rs, o_hs, do_rs, do_hs, lse_stride, (hipStream_t)stream))
+        return fail(LV_ELAUNCH, "delta launch failed");
+    return LV_OK;
+}
+
+extern "C" int lvattn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                          float* dq_accum, void* dk, void* dv, const int32_t* desc_dev, int n_blocks,
+                          int q_rows_total, int k_rows_total, int hq, int hkv, int d,
+                          int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                          int64_t do_rs, int64_t do_hs, int64_t dk_rs, int64_t dk_hs, int64_t dv_rs, int64_t dv_hs,
+                          int64_t lse_stride, float scale, int causal, int dkv_accum_f32, void* stream) {
+    if (int e = check_common(q, k, v, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
+    if (!dout || !lse || !delta || !dq_accum || !dk || !dv || !desc_dev) return fail(LV_EINVAL, "null pointer");
+    if (((uintptr_t)dout & 15) || ((do_rs | do_hs) & 7)) return fail(LV_EINVAL, "dout must be 16-byte aligned, strides % 8 == 0");
+    if ((((uintptr_t)dk | (uintptr_t)dv) & 15) || ((dk_rs | dk_hs | dv_rs | dv_hs) & 3))
+        return fail(LV_EINVAL, "dk/dv must be 16-byte aligned with strides % 4 == 0");
+    if ((uintptr_t)dq_accum & 15) return fail(LV_EINVAL, "dq_accum must be 16-byte aligned");
+    if (n_blocks < 0 || q_rows_total <= 0 || k_rows_total <= 0 || lse_stride < q_rows_total) return fail(LV_EINVAL, "bad sizes");
+    if (n_blocks == 0) return LV_OK;
+    BwdParams p;
+    p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.dout = (const __bf16*)dout;
+    p.lse = lse; p.delta = delta; p.dq = dq_accum; p.dk = dk; p.dv = dv;
+    p.desc = (const AttnDesc*)desc_dev;
+    p.n_blocks = n_blocks; p.hq = hq; p.hkv = hkv; p.group = hq / hkv;
+    p.q_rows_total = q_rows_total; p.k_rows_total = k_rows_total;
+    p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
+    p.do_rs = do_rs; p.do_hs = do_hs; p.dk_rs = dk_rs; p.dk_hs = dk_hs; p.dv_rs = dv_rs; p.dv_hs = dv_hs;
+    p.lse_stride = lse_stride; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+    if (lv_launch_bwd(p, d, causal, dkv_accum_f32, (hipStream_t)stream))
+        return fail(LV_ELAUNCH, "backward launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return LV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ring merge: (out_acc, lse_acc) <- combine with (out_blk, lse_blk)
+// one thread per 8 output elements
+// ---------------------------------------------------------------------------
+__global__ void lv_merge_kernel(float* __restrict__ out_acc, float* __restrict__ lse_acc,
+                                const __bf16* __restrict__ out_blk, const float* __restrict__ lse_blk,
+                                int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs, int64_t lse_stride) {
+    const int cpr = d / 8;  // 8-element chunks per (row, head)
+    int64_t total = (int64_t)rows * hq * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int ch = (int)(idx % cpr);
+        int64_t rh = idx / cpr;
+        int head = (int)(rh % hq);
+        int row = row0 + (int)(rh / hq);
+        float la = lse_acc[(int64_t)head * lse_stride + row];
+        float lb = lse_blk[(int64_t)head * lse_stride + row];
+        float m = fmaxf(la, lb);
+        float wa = 0.f, wb = 0.f, ln = -INFINITY;
+        if (m > -INFINITY) {
+            float ea = __expf(la - m), eb = __expf(lb - m);
+            float tot = ea + eb;
+            wa = ea / tot; wb = eb / tot;
+            ln = m + __logf(tot);
+        }
+        float* oa = out_acc + ((int64_t)row * hq + head) * d + ch * 8;
+        const __bf16* ob = out_blk + (int64_t)row * blk_rs + (int64_t)head * blk_hs + ch * 8;
+        f32x4 a0 = *reinterpret_cast<f32x4*>(oa), a1 = *reinterpret_cast<f32x4*>(oa + 4);
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(ob);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = a0[i] * wa + (float)b[i] * wb;
+            a1[i] = a1[i] * wa + (float)b[i + 4] * wb;
+        }
+        *reinterpret_cast<f32x4*>(oa) = a0;
+        *reinterpret_cast<f32x4*>(oa + 4) = a1;
+        // every chunk of a (row, head) computes the same lse; chunk 0 writes it after all
+        // chunks of this (row, head) in this thread's wave have read la (same wave: cpr <= 16
+        // consecutive threads), other waves never read this (row, head).
+        if (ch == 0) lse_acc[(int64_t)head * lse_stride + row] = ln;
+    }
+}
+
+extern "C" int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
+                            int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs,
+                            int64_t lse_stride, void* stream) {
+    if (!out_acc || !lse_acc || !out_blk || !lse_blk) return fail(LV_EINVAL, "null pointer");
+    if (d % 8 || rows < 0 || hq <= 0) return fail(LV_EINVAL, "bad shape");
+    if ((blk_rs | blk_hs) & 7) return fail(LV_EINVAL, "block strides must be multiples of 8");
+    if (rows == 0) return LV_OK;
+    int64_t total = (int64_t)rows * hq * (d / 8);
+    int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(lv_merge_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_acc, lse_acc,
+                       (const __bf16*)out_blk, lse_blk, row0, rows, hq, d, blk_rs, blk_hs, lse_stride);
+    return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "merge launch failed");
+}
+
+// ---------------------------------------------------------------------------
+// fp32 -> bf16 cast with output strides (dq_accum -> dq)
+// ---------------------------------------------------------------------------
+__global__ void lv_cast_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t rows, int heads, int d,
+                               int64_t rs, int64_t hs) {
+    const int cpr = d / 8;
+    int64_t total = rows * heads * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int ch = (int)(idx % cpr);
+        int64_t rh = idx / cpr;
+        int head = (int)(rh % heads);
+        int64_t row = rh / heads;
+        const float* s = src + idx * 8;
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = (__bf16)a0[i]; o[i + 4] = (__bf16)a1[i]; }
+        *reinterpret_cast<bf16x8*>(dst + row * rs + (int64_t)head * hs + ch * 8) = o;
+    }
+}
+
+extern "C" int lvattn_cast_f32_bf16(const float* src, void* dst, int rows, int heads, int d,
+                                    int64_t rs, int64_t hs, void* stream) {
+    if (!src || !dst) return fail(LV_EINVAL, "null pointer");
+    if (d % 8 || ((rs | hs) & 7) || ((uintptr_t)dst & 15)) return fail(LV_EINVAL, "bad alignment");
+    if (rows <= 0) return LV_OK;
+    int64_t total = (int64_t)rows * heads * (d / 8);
+    int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(lv_cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, (int64_t)rows, heads, d, rs, hs);
+    return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "cast launch failed");
+}
+
+// ---------------------------------------------------------------------------
+// pixel shuffle (scale 0.5) fused with the class-token drop.
+// Derived from the reference's view/permute chain: with the ViT grid indexed [w][h] (w = token / side, h = token % side)
+//   out[n][w/2][h/2][ (w%2)*2c + (h%2)*c + ch ] = in[n][w][h][ch]
+// i.e. output token (w/2)*(side/2) + (h/2), channel block (w%2)*2 + (h%2).
+// Pure 16-byte moves: one thread per 8 bf16.
+// ---------------------------------------------------------------------------
+__global__ void lv_pixel_shuffle_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int n, int side, int c,
+                                        int skip, int64_t in_image_stride) {
+    const int cpr = c / 8;
+    const int half = side / 2;
+    int64_t total = (int64_t)n * side * side * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int ch = (int)(idx % cpr);
+        int64_t t = idx / cpr;
+        int hh = (int)(t % side); t /= side;
+        int ww = (int)(t % side);
+        int img = (int)(t / side);
+        const __bf16* src = in + (int64_t)img * in_image_stride + ((int64_t)(skip + ww * side + hh)) * c + ch * 8;
+        int64_t otok = (int64_t)(ww / 2) * half + (hh / 2);
+        __bf16* dst = out + (((int64_t)img * half * half + otok) * 4 + ((ww & 1) * 2 + (hh & 1))) * c + ch * 8;
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    }
+}
+
+extern "C" int lv_pixel_shuffle(const void* in, void* out, int n, int side, int c, int skip,
+                                int64_t in_image_stride, void* stream) {
+    if (!in || !out) return fail(LV_EINVAL, "null pointer");
+    if (side <= 0 || (side & 1) || c % 8 || n < 0 || skip < 0) return fail(LV_EINVAL, "bad shape (side must be even, c %% 8 == 0)");
+    if ((in_image_stride & 7) || (((uintptr_t)in | (uintptr_t)out) & 15)) return fail(LV_EINVAL, "bad alignment");
+    if (((int64_t)skip * c) & 7) return fail(LV_EINVAL, "skip*c must be a multiple of 8");
+    if (n == 0) return LV_OK;
+    int64_t total = (int64_t)n * side * side * (c / 8);
+    int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(lv_pixel_shuffle_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)in, (__bf16*)out, n, side, c,
+                       skip, in_image_stride);
+    return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "pixel_shuffle launch failed");
+}
+
+// ---------------------------------------------------------------------------
+// row scatter / gather (16-byte or 4-byte granules)
+// ---------------------------------------------------------------------------
+template <typename VEC>
+__global__ void lv_move_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, const int64_t* __restrict__ src_index,
+                                    const int64_t* __restrict__ dst_index, int64_t n, int64_t row_bytes, int64_t src_rows,
+                                    int64_t dst_rows) {
+    const int64_t vpr = row_bytes / sizeof(VEC);
+    int64_t total = n * vpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = idx / vpr, e = idx % vpr;
+        int64_t s = src_index ? src_index[i] : i;
+        int64_t t = dst_index ? dst_index[i] : i;
+        if (s < 0) s += src_rows;  // torch-style negative indices
+        if (t < 0) t += dst_rows;
+        if (s < 0 || s >= src_rows || t < 0 || t >= dst_rows) continue;  // out-of-range rows are skipped
+        reinterpret_cast<VEC*>(dst + t * row_bytes)[e] = reinterpret_cast<const VEC*>(src + s * row_bytes)[e];
+    }
+}
+
+static int move_rows(const void* src, void* dst, const int64_t* si, const int64_t* di, int64_t n, int64_t row_bytes,
+                     int64_t src_rows, int64_t dst_rows, void* stream) {
+    if (!src || !dst) return fail(LV_EINVAL, "null pointer");
+    if (n < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(LV_EINVAL, "row bytes must be a positive multiple of 4");
+    if (n == 0) return LV_OK;
+    bool wide = !(row_bytes & 15) && !(((uintptr_t)src | (uintptr_t)dst) & 15);
+    int64_t total = n * (row_bytes / (wide ? 16 : 4));
+    int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    if (wide)
+        hipLaunchKernelGGL(lv_move_rows_kernel<u32x4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)src, (char*)dst, si, di, n,
+                           row_bytes, src_rows, dst_rows);
+    else
+        hipLaunchKernelGGL(lv_move_rows_kernel<uint32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)src, (char*)dst, si, di,
+                           n, row_bytes, src_rows, dst_rows);
+    return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "row move launch failed");
+}
+
+extern "C" int lv_scatter_rows(const void* src, void* dst, const int64_t* src_index, const int64_t* dst_index,
+                               int64_t n, int width, int64_t src_rows, int64_t dst_rows, void* stream) {
+    if (!dst_index) return fail(LV_EINVAL, "dst_index is null");
+    if (width <= 0 || (width & 1)) return fail(LV_EINVAL, "width must be a positive even number of bf16 elements");
+    return move_rows(src, dst, src_index, dst_index, n, (int64_t)width * 2, src_rows, dst_rows, stream);
+}
+
+extern "C" int lv_gather_rows(const void* src, void* dst, const int64_t* index, int64_t n,
+                              int64_t row_bytes, int64_t src_rows, void* stream) {
+    if (!index) return fail(LV_EINVAL, "index is null");
+    return move_rows(src, dst, index, nullptr, n, row_bytes, src_rows, n, stream);
+}

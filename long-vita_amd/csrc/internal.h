@@ -1,0 +1,37 @@
+// Internal launch interfaces between the translation units of liblvattn.
+#pragma once
+#include "common.h"
+
+struct FwdParams {
+    const __bf16* q;
+    const __bf16* k;
+    const __bf16* v;
+    __bf16* o;
+    float* lse;
+    const AttnDesc* desc;
+    int n_blocks, hq, hkv, group;  // group = hq / hkv
+    int q_rows_total, k_rows_total;
+    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, o_rs, o_hs, lse_stride;
+    float scale, scale_log2e;
+};
+int lv_launch_fwd(const FwdParams& p, int d, int causal, hipStream_t stream);
+
+struct BwdParams {
+    const __bf16* q;
+    const __bf16* k;
+    const __bf16* v;
+    const __bf16* dout;
+    const float* lse;
+    const float* delta;
+    float* dq;   // fp32 [rows, hq, d] contiguous, atomically accumulated
+    void* dk;    // bf16 (stored) or fp32 (accumulated)
+    void* dv;
+    const AttnDesc* desc;
+    int n_blocks, hq, hkv, group;
+    int q_rows_total, k_rows_total;
+    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs, dk_rs, dk_hs, dv_rs, dv_hs, lse_stride;
+    float scale, scale_log2e;
+};
+int lv_launch_bwd(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);
+int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows, int hq, int d, int64_t o_rs, int64_t o_hs,
+                        int64_t do_rs, int64_t do_hs, int64_t lse_stride, hipStream_t stream);

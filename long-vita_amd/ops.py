@@ -1,0 +1,275 @@
+"""Tensor-level wrappers over the C ABI (include/lvattn.h).
+
+PyTorch is used here for device memory, streams and autograd bookkeeping only:
+every arithmetic step runs in the HIP kernels of liblvattn.so.  Tensors are
+passed as raw pointers + element strides; nothing is copied unless a tensor's
+last dimension is not contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LV_BWD_BLOCK_N, LV_DESC_INTS, LV_FWD_BLOCK_M, LvAttnError, check
+
+_I32P = C.POINTER(C.c_int32)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: torch.Tensor | None) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise LvAttnError("liblvattn kernels need tensors on the GPU (there is no CPU fallback)")
+
+
+def _last_contig(t: torch.Tensor) -> torch.Tensor:
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# block descriptors
+# ---------------------------------------------------------------------------
+def cu_seqlens_from_actual_seq_len(actual_seq_len: Sequence[int]) -> list:
+    """[0] + cumulative end offsets.  The reference hands ``actual_seq_len`` (end
+    offsets without the leading 0) to the kernel as actual_seq_qlen/kvlen
+    (lcvlm_modellink/core/transformer/dot_product_attention.py:333,363-364)."""
+    return [0] + [int(x) for x in actual_seq_len]
+
+
+def build_blocks_host(cu_seqlens: Sequence[int], causal: bool, backward: bool = False) -> np.ndarray:
+    """Descriptors [n, 8] int32 (host) for packed segments, heaviest first."""
+    cu = np.ascontiguousarray(np.asarray(cu_seqlens, dtype=np.int32))
+    n_seg = cu.shape[0] - 1
+    if n_seg < 0:
+        raise LvAttnError("cu_seqlens must hold at least one entry")
+    blk = LV_BWD_BLOCK_N if backward else LV_FWD_BLOCK_M
+    lens = np.diff(cu.astype(np.int64)) if n_seg else np.zeros(0, np.int64)
+    max_blocks = int(np.sum((np.maximum(lens, 0) + blk - 1) // blk)) + 1
+    out = np.zeros((max_blocks, LV_DESC_INTS), dtype=np.int32)
+    fn = _lib.lib().lv_build_bwd_blocks if backward else _lib.lib().lv_build_fwd_blocks
+    n = check(fn(cu.ctypes.data_as(_I32P), n_seg, int(causal), out.ctypes.data_as(_I32P), max_blocks), "lv_build_blocks")
+    return out[:n]
+
+
+def build_rect_blocks_host(q_row0: int, q_len: int, k_row0: int, k_len: int, causal: bool, shift: int = 0,
+                           backward: bool = False) -> np.ndarray:
+    """Descriptors for one rectangle of the score matrix (a ring step)."""
+    blk = LV_BWD_BLOCK_N if backward else LV_FWD_BLOCK_M
+    span = k_len if backward else q_len
+    max_blocks = (span + blk - 1) // blk + 1
+    out = np.zeros((max_blocks, LV_DESC_INTS), dtype=np.int32)
+    fn = _lib.lib().lv_build_bwd_blocks_rect if backward else _lib.lib().lv_build_fwd_blocks_rect
+    n = check(fn(q_row0, q_len, k_row0, k_len, int(causal), shift, out.ctypes.data_as(_I32P), max_blocks), "lv_build_blocks_rect")
+    return out[:n]
+
+
+class _BlockCache:
+    """Device copies of descriptor tables, keyed by (segments, causal, direction, device)."""
+
+    def __init__(self, capacity: int = 64):
+        self.capacity = capacity
+        self.store: OrderedDict = OrderedDict()
+
+    def get(self, key, make):
+        hit = self.store.get(key)
+        if hit is not None:
+            self.store.move_to_end(key)
+            return hit
+        val = make()
+        self.store[key] = val
+        if len(self.store) > self.capacity:
+            self.store.popitem(last=False)
+        return val
+
+
+_blocks = _BlockCache()
+
+
+def blocks_on_device(cu_seqlens: Sequence[int], causal: bool, backward: bool, device) -> torch.Tensor:
+    key = ("seg", tuple(int(x) for x in cu_seqlens), bool(causal), bool(backward), str(device))
+    return _blocks.get(key, lambda: torch.from_numpy(build_blocks_host(cu_seqlens, causal, backward)).to(device))
+
+
+def rect_blocks_on_device(q_row0, q_len, k_row0, k_len, causal, shift, backward, device) -> torch.Tensor:
+    key = ("rect", q_row0, q_len, k_row0, k_len, bool(causal), shift, bool(backward), str(device))
+    return _blocks.get(key, lambda: torch.from_numpy(
+        build_rect_blocks_host(q_row0, q_len, k_row0, k_len, causal, shift, backward)).to(device))
+
+
+# ---------------------------------------------------------------------------
+# raw launches
+# ---------------------------------------------------------------------------
+def _check_qkv(q, k, v):
+    _require_gpu(q, k, v)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise LvAttnError("q, k, v must be bfloat16")
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
+        raise LvAttnError("q, k, v must be [rows, heads, head_dim]")
+    if k.shape != v.shape or q.shape[2] != k.shape[2]:
+        raise LvAttnError(f"shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+
+
+def attn_fwd_launch(q, k, v, desc: torch.Tensor, scale: float, causal: bool, out=None, lse=None):
+    """q [Rq,Hq,D], k/v [Rk,Hkv,D] bf16 (any row/head stride), desc int32 [n,8] on
+    the device.  Returns (out [Rq,Hq,D] bf16, lse [Hq,Rq] fp32).  Rows no descriptor
+    covers are left untouched in ``out``/``lse`` when those are passed in."""
+    q, k, v = _last_contig(q), _last_contig(k), _last_contig(v)
+    _check_qkv(q, k, v)
+    rq, hq, d = q.shape
+    rk, hkv, _ = k.shape
+    if out is None:
+        out = torch.empty((rq, hq, d), dtype=torch.bfloat16, device=q.device)
+    if lse is None:
+        lse = torch.empty((hq, rq), dtype=torch.float32, device=q.device)
+    check(_lib.lib().lvattn_fwd(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(desc), desc.shape[0],
+        rq, rk, hq, hkv, d,
+        q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+        out.stride(0), out.stride(1), lse.stride(0), float(scale), int(causal), _stream()), "lvattn_fwd")
+    return out, lse
+
+
+def attn_bwd_launch(q, k, v, out, dout, lse, desc_bwd: torch.Tensor, scale: float, causal: bool,
+                    dq_accum=None, dk=None, dv=None, delta=None, dkv_accum_f32: bool = False):
+    """Backward of ``attn_fwd_launch``.  Returns (dq_accum fp32 [Rq,Hq,D], dk, dv).
+    ``dk``/``dv`` are bf16 [Rk,Hkv,D] (written) or, with ``dkv_accum_f32``, fp32
+    buffers that are added to.  ``dq_accum`` is added to (zero it first)."""
+    q, k, v, dout, out = (_last_contig(t) for t in (q, k, v, dout, out))
+    _check_qkv(q, k, v)
+    rq, hq, d = q.shape
+    rk, hkv, _ = k.shape
+    L = _lib.lib()
+    if delta is None:
+        delta = torch.empty((hq, lse.stride(0)), dtype=torch.float32, device=q.device)
+        check(L.lvattn_bwd_delta(_ptr(out), _ptr(dout), _ptr(delta), rq, hq, d, out.stride(0), out.stride(1),
+                                 dout.stride(0), dout.stride(1), delta.stride(0), _stream()), "lvattn_bwd_delta")
+    if dq_accum is None:
+        dq_accum = torch.zeros((rq, hq, d), dtype=torch.float32, device=q.device)
+    if dk is None:
+        dt = torch.float32 if dkv_accum_f32 else torch.bfloat16
+        dk = torch.zeros((rk, hkv, d), dtype=dt, device=q.device)
+        dv = torch.zeros((rk, hkv, d), dtype=dt, device=q.device)
+    check(L.lvattn_bwd(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dq_accum), _ptr(dk), _ptr(dv),
+        _ptr(desc_bwd), desc_bwd.shape[0], rq, rk, hq, hkv, d,
+        q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+        dout.stride(0), dout.stride(1), dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1),
+        lse.stride(0), float(scale), int(causal), int(dkv_accum_f32), _stream()), "lvattn_bwd")
+    return dq_accum, dk, dv, delta
+
+
+def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor | None = None) -> torch.Tensor:
+    """src fp32 [rows, heads, d] contiguous -> bf16 (dst may be a strided view)."""
+    rows, heads, d = src.shape
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().lvattn_cast_f32_bf16(_ptr(src), _ptr(dst), rows, heads, d, dst.stride(0), dst.stride(1), _stream()),
+          "lvattn_cast_f32_bf16")
+    return dst
+
+
+def merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0: int, rows: int):
+    """In-place log-sum-exp merge of a block result into the running fp32 result."""
+    _, hq, d = out_acc.shape
+    check(_lib.lib().lvattn_merge(_ptr(out_acc), _ptr(lse_acc), _ptr(out_blk), _ptr(lse_blk), row0, rows, hq, d,
+                                  out_blk.stride(0), out_blk.stride(1), lse_acc.stride(0), _stream()), "lvattn_merge")
+
+
+# ---------------------------------------------------------------------------
+# autograd: packed variable-length attention
+# ---------------------------------------------------------------------------
+class _VarlenAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens, scale, causal):
+        desc = blocks_on_device(cu_seqlens, causal, False, q.device)
+        total = q.shape[0]
+        covered = len(cu_seqlens) > 1 and cu_seqlens[0] == 0 and cu_seqlens[-1] == total
+        out = None if covered else torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+        lse = None if covered else torch.full((q.shape[1], total), float("-inf"), dtype=torch.float32, device=q.device)
+        out, lse = attn_fwd_launch(q, k, v, desc, scale, causal, out, lse)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cu_seqlens = tuple(cu_seqlens)
+        ctx.scale = scale
+        ctx.causal = causal
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        q, k, v, out, lse = ctx.saved_tensors
+        desc = blocks_on_device(ctx.cu_seqlens, ctx.causal, True, q.device)
+        dq_acc, dk, dv, _ = attn_bwd_launch(q, k, v, out, dout, lse, desc, ctx.scale, ctx.causal)
+        dq = cast_f32_to_bf16(dq_acc)
+        return dq, dk, dv, None, None, None
+
+
+def varlen_attention(q, k, v, cu_seqlens: Sequence[int], scale: float | None = None, causal: bool = True):
+    """Packed variable-length attention, one block per segment of ``cu_seqlens``.
+    q [T,Hq,D], k/v [T,Hkv,D] bf16 -> (out [T,Hq,D] bf16, lse [Hq,T] fp32); differentiable in q, k, v."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    return _VarlenAttention.apply(q, k, v, tuple(int(x) for x in cu_seqlens), float(scale), bool(causal))
+
+
+# ---------------------------------------------------------------------------
+# data movement
+# ---------------------------------------------------------------------------
+def pixel_shuffle_tokens(vit_output: torch.Tensor, skip: int = 1) -> torch.Tensor:
+    """[N, skip + side*side, C] bf16 -> [N, (side/2)^2, 4C]: class-token drop + pixel
+    shuffle with scale 0.5 (lcvlm_modellink/pretrain_lcvlm.py:463-470, 546-556)."""
+    _require_gpu(vit_output)
+    if vit_output.dtype != torch.bfloat16:
+        raise LvAttnError("pixel_shuffle_tokens expects bfloat16")
+    x = vit_output if (vit_output.stride(2) == 1 and vit_output.stride(1) == vit_output.shape[2]) else vit_output.contiguous()
+    n, t, c = x.shape
+    side = int(round(math.sqrt(t - skip)))
+    if side * side != t - skip:
+        raise LvAttnError(f"{t - skip} tokens do not form a square grid")
+    out = torch.empty((n, (side // 2) ** 2, 4 * c), dtype=x.dtype, device=x.device)
+    check(_lib.lib().lv_pixel_shuffle(_ptr(x), _ptr(out), n, side, c, skip, x.stride(0), _stream()), "lv_pixel_shuffle")
+    return out
+
+
+def scatter_rows_(dst: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor, src_index: torch.Tensor | None = None):
+    """dst[dst_index[i]] = src[src_index[i]] over 2-D row views (bf16, contiguous rows)."""
+    _require_gpu(dst, src, dst_index)
+    if dst.dtype != torch.bfloat16 or src.dtype != torch.bfloat16:
+        raise LvAttnError("scatter_rows_ expects bfloat16")
+    if not dst.is_contiguous():
+        raise LvAttnError("scatter_rows_ needs a contiguous destination")
+    src = src.contiguous()
+    dst_index = dst_index.to(torch.int64).contiguous()
+    if src_index is not None:
+        src_index = src_index.to(torch.int64).contiguous()
+    n = dst_index.numel()
+    width = dst.shape[-1]
+    check(_lib.lib().lv_scatter_rows(_ptr(src), _ptr(dst), _ptr(src_index), _ptr(dst_index), n, width,
+                                     src.numel() // width, dst.numel() // width, _stream()), "lv_scatter_rows")
+    return dst
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """out[i] = src[index[i]] along dim 0 (any dtype whose row size is a multiple of 4 bytes)."""
+    _require_gpu(src, index)
+    src = src.contiguous()
+    index = index.to(torch.int64).contiguous()
+    row_bytes = src[0].numel() * src.element_size() if src.shape[0] else 0
+    out = torch.empty((index.numel(),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if index.numel() == 0 or row_bytes == 0:
+        return out
+    check(_lib.lib().lv_gather_rows(_ptr(src), _ptr(out), _ptr(index), index.numel(), row_bytes, src.shape[0], _stream()),
+          "lv_gather_rows")
+    return out

@@ -1,0 +1,130 @@
+"""GPU parity tests of the attention kernels (through the C ABI) against the CPU
+oracle.  Tolerances are the ones the project states for bf16: max error relative
+to the tensor's max magnitude <= 2e-2 for outputs and gradients, LSE within 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention_ref as A
+
+REL_TOL = 2e-2
+LSE_TOL = 1e-3
+
+
+def rel_err(got: torch.Tensor, ref: np.ndarray) -> float:
+    g = got.detach().float().cpu().numpy().astype(np.float64)
+    return float(np.abs(g - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def make_qkv(T, Hq, Hkv, D, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    q = (torch.randn(T, Hq, D, generator=g) * scale).to(torch.bfloat16)
+    k = (torch.randn(T, Hkv, D, generator=g) * scale).to(torch.bfloat16)
+    v = (torch.randn(T, Hkv, D, generator=g) * scale).to(torch.bfloat16)
+    return q, k, v
+
+
+CASES = [
+    # name, cu_seqlens, Hq, Hkv, D, causal
+    ("one_tile", [0, 64], 2, 1, 128, True),
+    ("ragged", [0, 100, 356, 357, 700, 1290], 10, 2, 128, True),
+    ("multi_block", [0, 258, 1290, 3000], 5, 1, 128, True),
+    ("dense_d64", [0, 1025], 4, 4, 64, False),
+    ("dense_d128", [0, 300, 900], 4, 2, 128, False),
+    ("causal_d64", [0, 130, 700], 4, 2, 64, True),
+]
+
+
+@pytest.mark.parametrize("name,cu,Hq,Hkv,D,causal", CASES, ids=[c[0] for c in CASES])
+def test_forward_matches_oracle(name, cu, Hq, Hkv, D, causal):
+    from long_vita_amd import ops
+    T = cu[-1]
+    q, k, v = make_qkv(T, Hq, Hkv, D, seed=hash(name) % 1000)
+    scale = A.default_scale(D)
+    ref_o, ref_lse = A.varlen_attention(q, k, v, cu, scale, causal)
+    out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), cu, scale, causal)
+    torch.cuda.synchronize()
+    assert rel_err(out, ref_o) <= REL_TOL
+    assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL
+
+
+def test_forward_exact_layout_integers():
+    """Small-integer data: every product and sum is exact in bf16/fp32, so any
+    fragment-layout mistake shows as a large error rather than rounding noise."""
+    from long_vita_amd import ops
+    T, Hq, Hkv, D = 192, 2, 1, 128
+    g = torch.Generator().manual_seed(5)
+    q = torch.zeros(T, Hq, D)
+    k = torch.zeros(T, Hkv, D)
+    # one-hot rows: q.k is 0 except where the hot columns agree -> softmax over {0, c}
+    qi = torch.randint(0, D, (T, Hq), generator=g)
+    ki = torch.randint(0, D, (T, Hkv), generator=g)
+    q.scatter_(2, qi[..., None], 8.0)
+    k.scatter_(2, ki[..., None], 1.0)
+    v = torch.randint(-4, 5, (T, Hkv, D), generator=g).float()
+    q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], 1.0, True)
+    out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], 1.0, True)
+    assert rel_err(out, ref_o) <= 1e-2
+    assert np.abs(lse.cpu().numpy() - ref_lse).max() <= LSE_TOL
+
+
+def test_forward_strided_views_no_copy():
+    """q/k/v as views into one fused [T, Hkv, (G+2)*D] projection, as Megatron hands them over."""
+    from long_vita_amd import ops
+    T, Hkv, G, D = 700, 2, 5, 128
+    g = torch.Generator().manual_seed(11)
+    fused = torch.randn(T, Hkv, (G + 2) * D, generator=g).to(torch.bfloat16).cuda()
+    q = fused[:, :, :G * D].reshape(T, Hkv, G, D)          # not a view-compatible reshape -> copy (as Megatron does)
+    q = q.reshape(T, Hkv * G, D)
+    k = fused[:, :, G * D:(G + 1) * D]
+    v = fused[:, :, (G + 1) * D:]
+    assert not k.is_contiguous()
+    cu = [0, 300, 700]
+    ref_o, ref_lse = A.varlen_attention(q.cpu(), k.cpu(), v.cpu(), cu, A.default_scale(D), True)
+    out, lse = ops.varlen_attention(q, k, v, cu, None, True)
+    assert rel_err(out, ref_o) <= REL_TOL
+    assert np.abs(lse.cpu().numpy() - ref_lse).max() <= LSE_TOL
+
+
+def test_forward_matches_reference_eager_golden(golden_dir):
+    """Against outputs of the reference's own eager attention wrapper."""
+    from long_vita_amd import ops
+    g = np.load(os.path.join(golden_dir, "eager_attention.npz"))
+    for name, sq, b, np_, ng, hn in [("mha_d64", 65, 1, 4, 4, 64), ("qwen_ratio", 96, 1, 10, 2, 128)]:
+        q, k, v = (torch.from_numpy(g[f"{name}.{x}"])[:, 0].to(torch.bfloat16).cuda() for x in "qkv")
+        out, _ = ops.varlen_attention(q, k, v, [0, sq], None, True)
+        assert rel_err(out.reshape(sq, 1, -1), g[f"{name}.out"].astype(np.float64)) <= REL_TOL
+        out, _ = ops.varlen_attention(q, k, v, [0, sq], None, False)
+        assert rel_err(out.reshape(sq, 1, -1), g[f"{name}.out_nomask"].astype(np.float64)) <= REL_TOL
+
+
+BWD_CASES = [
+    ("bwd_one", [0, 128], 2, 1, 128, True),
+    ("bwd_ragged", [0, 100, 356, 357, 700, 1000], 10, 2, 128, True),
+    ("bwd_dense_d64", [0, 1025], 2, 2, 64, False),
+    ("bwd_dense_d128", [0, 200, 520], 4, 2, 128, False),
+    ("bwd_causal_d64", [0, 130, 450], 4, 2, 64, True),
+]
+
+
+@pytest.mark.parametrize("name,cu,Hq,Hkv,D,causal", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_backward_matches_oracle(name, cu, Hq, Hkv, D, causal):
+    from long_vita_amd import ops
+    T = cu[-1]
+    q, k, v = make_qkv(T, Hq, Hkv, D, seed=hash(name) % 1000)
+    g = torch.Generator().manual_seed(99)
+    do = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale, causal)
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out, _ = ops.varlen_attention(qc, kc, vc, cu, scale, causal)
+    out.backward(do.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(qc.grad, rdq) <= REL_TOL
+    assert rel_err(kc.grad, rdk) <= REL_TOL
+    assert rel_err(vc.grad, rdv) <= REL_TOL
