@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark of the long-context attention hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--seq S]
+
+Default workload ``prefill_1m``: one layer's causal attention prefill over a
+1,048,576-token packed context with Qwen2.5-14B heads (40 query / 8 KV heads,
+d = 128, bf16), single causal segment (the reference's stage-3/4 semantics:
+joint packing, no mask reset).  With N > 1 the sequence is zig-zag sharded over
+N ranks (context parallel, CP = N) and the KV blocks travel round a ring of
+RCCL send/recv; the total work is fixed, so scaling is "strong".
+A "step" is one full attention forward over the whole context.
+
+Rank 0 prints ONE JSON line: metric tokens/s for the whole job, plus
+  roofline     achieved TFLOP/s of the forward kernel (algorithmic FLOPs
+               2*d*Hq*S^2 for a causal segment / mean kernel time from HIP
+               events on the launch stream) against the 2.5 PFLOP/s dense
+               bf16 MFMA peak,
+  cpu_baseline the reference's eager PyTorch attention (oracle restatement)
+               timed on the host cores on a bounded row sample, extrapolated.
+
+Other workloads (``cfg3_fwd_bwd``: 128K packed tokens forward+backward;
+``cfg2_vit``: InternViT-300M attention on 64 frames) are for profiling; the
+judged line is the default one.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (spec), TFLOP/s
+HQ, HKV, D = 40, 8, 128
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit"])
+    ap.add_argument("--seq", type=int, default=0, help="override the sequence length (testing)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if n > 1 and world != n:
+        raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run); got {world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x: float, world) -> float:
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def causal_fwd_flops(lengths, hq=HQ, d=D):
+    return sum(2.0 * d * hq * float(L) * float(L) for L in lengths)
+
+
+def cpu_baseline(seq, rows=1024, heads=(0, 1)):
+    """The reference's eager attention path (oracle restatement of
+    dot_product_attention.py:183-286) on ``rows`` query rows x all keys x
+    ``heads`` query heads, extrapolated linearly in rows x heads: the eager path
+    materialises the whole [sq, sk] score matrix before masking, so the cost per
+    row does not depend on the row's position."""
+    from oracle import attention_ref as A
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1)
+    rows = max(1, min(rows, seq))
+    heads = list(heads)
+    kv_heads = [h // (HQ // HKV) for h in heads]
+    row0 = (seq - rows) // 2
+    q = torch.randn(rows, 1, len(heads), D, generator=g) * 0.5
+    k = torch.randn(seq, 1, len(heads), D, generator=g) * 0.5     # K/V already expanded per query head,
+    v = torch.randn(seq, 1, len(heads), D, generator=g) * 0.5     # as repeat_interleave leaves them
+    mask = (torch.arange(seq)[None, :] > (torch.arange(rows)[:, None] + row0))[None, None]
+
+    def run():
+        return A.eager_attention(q, k, v, mask, math.sqrt(D))
+    run()  # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    full = dt * (seq / rows) * (HQ / len(heads))
+    return {"value": seq / full, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{rows} query rows x {seq} keys x {len(heads)} of {HQ} heads, fp32 eager baddbmm/softmax/bmm, "
+                      f"{dt:.2f}s measured, extrapolated linearly in rows x heads"}
+
+
+def main():
+    args = parse()
+    rank, world, local = dist_setup(args.gpus)
+    from long_vita_amd import ops
+    dev = torch.device("cuda", local)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def rnd(*shape):
+        return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+
+    wl = args.workload
+    extra = {}
+    kernel_ms = []
+    if wl == "prefill_1m":
+        S = args.seq or 1048576
+        cp = world
+        s_loc = S // cp
+        q, k, v = rnd(s_loc, HQ, D), rnd(s_loc, HKV, D), rnd(s_loc, HKV, D)
+        scale = 1.0 / math.sqrt(D)
+        if cp == 1:
+            cu = [0, S]
+            desc = ops.blocks_on_device(cu, True, False, dev)
+            out = torch.empty_like(q)
+            lse = torch.empty((HQ, S), dtype=torch.float32, device=dev)
+
+            def step():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.attn_fwd_launch(q, k, v, desc, scale, True, out, lse)
+                e1.record()
+                return e0, e1
+        else:
+            from long_vita_amd.ring_context_parallel import RingAttention
+            import torch.distributed as dist
+            ring = RingAttention(dist.group.WORLD, cp, rank, causal=True)
+
+            def step():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ring.forward(q.view(s_loc, 1, HQ * D), k.view(s_loc, 1, HKV * D), v.view(s_loc, 1, HKV * D), HQ, scale)
+                e1.record()
+                return e0, e1
+        tokens_per_step = S
+        flops_per_step = causal_fwd_flops([S])
+        flops_per_gpu_step = flops_per_step / cp
+        config = {"workload": "prefill_1m: causal attention forward, single 1M-token segment" if not args.seq else f"prefill S={S}",
+                  "seq_len": S, "q_heads": HQ, "kv_heads": HKV, "head_dim": D, "parallelism": f"cp{cp}", "layers_per_step": 1}
+        scaling = "strong"
+    elif wl in ("cfg3_fwd_bwd", "cfg3_packed"):
+        S = args.seq or 131072
+        if wl == "cfg3_packed":
+            import numpy as np
+            rs = np.random.RandomState(1234)
+            lens = []
+            while sum(lens) < S:
+                lens.append(int(math.exp(rs.uniform(math.log(256), math.log(32768)))))
+            cu = [0]
+            for L in lens:
+                cu.append(min(S, cu[-1] + L))
+            cu[-1] = S
+        else:
+            cu = [0, S]
+        q, k, v = (rnd(S, HQ, D).requires_grad_(True), rnd(S, HKV, D).requires_grad_(True), rnd(S, HKV, D).requires_grad_(True))
+        do = rnd(S, HQ, D)
+        scale = 1.0 / math.sqrt(D)
+
+        def step():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            q.grad = k.grad = v.grad = None
+            e0.record()
+            out, _ = ops.varlen_attention(q, k, v, cu, scale, True)
+            out.backward(do)
+            e1.record()
+            return e0, e1
+        lens = [b - a for a, b in zip(cu[:-1], cu[1:])]
+        tokens_per_step = S
+        flops_per_step = 3.5 * causal_fwd_flops(lens)
+        flops_per_gpu_step = flops_per_step
+        config = {"workload": f"{wl}: varlen causal attention fwd+bwd, {len(lens)} segment(s)", "seq_len": S, "q_heads": HQ, "kv_heads": HKV,
+                  "head_dim": D, "parallelism": "cp1"}
+        scaling = "weak"
+    else:  # cfg2_vit: 24 layers x 64 frames x 16 heads x 1025 tokens, d=64, non-causal
+        B, H, Sv, Dv, layers = 64, 16, 1025, 64, 24
+        qkv = [rnd(Sv, B * H, Dv) for _ in range(3)]
+        desc = ops.blocks_on_device([0, Sv], False, False, dev)
+        out = torch.empty_like(qkv[0])
+        lse = torch.empty((B * H, Sv), dtype=torch.float32, device=dev)
+        scale = 1.0 / math.sqrt(Dv)
+
+        def step():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(layers):
+                ops.attn_fwd_launch(qkv[0], qkv[1], qkv[2], desc, scale, False, out, lse)
+            e1.record()
+            return e0, e1
+        tokens_per_step = B * Sv
+        flops_per_step = layers * B * H * 4.0 * Dv * Sv * Sv
+        flops_per_gpu_step = flops_per_step
+        config = {"workload": "cfg2_vit: InternViT-300M attention, 64 frames x 24 layers", "frames": B, "heads": H, "head_dim": Dv, "seq_len": Sv}
+        scaling = "weak"
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    events = [step() for _ in range(args.steps)]
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    mean_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    mean_kernel_s = max_over_ranks(mean_kernel_s, world)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        achieved = flops_per_gpu_step / mean_kernel_s / 1e12
+        res = {
+            "metric": "attention prefill tokens/sec (node) at 1M ctx" if wl == "prefill_1m" else f"attention tokens/sec ({wl})",
+            "value": tokens_per_step * args.steps / dt, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": config,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "note": "algorithmic FLOPs per GPU per step / mean device time per step (HIP events on the launch stream)"},
+        }
+        if not args.no_cpu_baseline and wl == "prefill_1m":
+            res["cpu_baseline"] = cpu_baseline(config["seq_len"])
+        print(json.dumps(res), flush=True)
+    barrier(world)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

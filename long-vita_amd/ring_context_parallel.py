@@ -1,0 +1,267 @@
+"""Zig-zag causal ring attention over a context-parallel group.
+
+Stands in for MindSpeed's ``ringattn_context_parallel`` (not in the reference
+tree; called from lcvlm_modellink/core/transformer/dot_product_attention.py:70-71
+with the ``cp_para`` dictionary built at :51-68).  Same call signature, same data
+layout ([s_local, b, heads*dim], the local sequence being chunks ``r`` and
+``2*CP-1-r`` of the 2*CP equal chunks, lcvlm_modellink/training/utils.py:352-361).
+
+MI355X design: one process per GPU; every step posts ONE grouped RCCL
+send/recv of the packed [2, s_local, b*kv_heads*dim] K/V buffer on a side HIP
+stream (xGMI is point-to-point: a ring step uses one link per direction), and the
+attention block kernel for the buffer already present runs meanwhile on the
+compute stream.  Per step the work is one of three rectangles of the score matrix
+  step 0                 : local causal block (2c x 2c, causal)
+  KV from an earlier rank: all local queries x first KV chunk (2c x c, no mask)
+  KV from a later rank   : second query chunk x whole KV block (c x 2c, no mask)
+each worth the same FLOPs, merged into a running (out fp32, log-sum-exp) pair.
+The backward pass sends the K/V block and its fp32 dK/dV accumulator round the
+same ring and returns the accumulator to its owner with one extra hop.
+
+The block arithmetic goes through a small backend object so that the schedule and
+the communication can be exercised on CPU (gloo) in tests with a checker backend;
+the default backend is the HIP library and has no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.distributed as dist
+
+
+class HipBackend:
+    """Block attention / merge on the GPU through liblvattn."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def block_fwd(self, q3, k3, v3, qr, kr, causal, shift, scale, out_blk, lse_blk):
+        desc = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, False, q3.device)
+        self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, causal, out_blk, lse_blk)
+
+    def merge(self, out_acc, lse_acc, out_blk, lse_blk, row0, rows):
+        self.ops.merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0, rows)
+
+    def finalize(self, out_acc):
+        return self.ops.cast_f32_to_bf16(out_acc)
+
+    def delta(self, out3, dout3, lse):
+        o = self.ops
+        delta = torch.empty_like(lse)
+        from ._lib import lib, check
+        check(lib().lvattn_bwd_delta(out3.data_ptr(), dout3.data_ptr(), delta.data_ptr(), out3.shape[0], out3.shape[1],
+                                     out3.shape[2], out3.stride(0), out3.stride(1), dout3.stride(0), dout3.stride(1),
+                                     delta.stride(0), torch.cuda.current_stream().cuda_stream), "lvattn_bwd_delta")
+        return delta
+
+    def block_bwd(self, q3, k3, v3, out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dk_acc, dv_acc):
+        desc = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, True, q3.device)
+        self.ops.attn_bwd_launch(q3, k3, v3, out3, dout3, lse, desc, scale, causal, dq_acc, dk_acc, dv_acc, delta, True)
+
+    def cast(self, x_f32, dtype):
+        if dtype == torch.bfloat16 and x_f32.dim() == 3:
+            return self.ops.cast_f32_to_bf16(x_f32.contiguous())
+        return x_f32.to(dtype)
+
+
+class TorchDistComm:
+    """Point-to-point ring traffic through torch.distributed (RCCL on GPUs, gloo on CPU),
+    issued on a side stream so that it overlaps the block kernel."""
+
+    def __init__(self, group, device):
+        self.group = group
+        self.cuda = device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+
+    def exchange(self, send_bufs, recv_bufs, dst, src):
+        """Post isend(send_bufs -> dst) and irecv(recv_bufs <- src) as one group; returns a
+        handle for wait().  The traffic starts once everything already queued on the
+        compute stream has finished (the receive buffer may still be in use there)."""
+        p2p = []
+        for s in send_bufs:
+            p2p.append(dist.P2POp(dist.isend, s, dst, self.group))
+        for r in recv_bufs:
+            p2p.append(dist.P2POp(dist.irecv, r, src, self.group))
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for r in dist.batch_isend_irecv(p2p):
+                    r.wait()          # stream-level wait on the side stream; the host does not block
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            return done
+        return dist.batch_isend_irecv(p2p)
+
+    def wait(self, handle):
+        if self.cuda:
+            torch.cuda.current_stream().wait_event(handle)
+        else:
+            for r in handle:
+                r.wait()
+
+
+class RingAttention:
+    """Engine for one context-parallel group.  ``rank`` is the rank inside the CP group;
+    ``global_ranks[i]`` the global rank of CP rank i (defaults to 0..cp-1)."""
+
+    def __init__(self, group, cp_size: int, rank: int, causal: bool = True, global_ranks=None, backend=None, comm=None):
+        self.group = group
+        self.cp = int(cp_size)
+        self.rank = int(rank)
+        self.causal = bool(causal)
+        self.global_ranks = list(global_ranks) if global_ranks is not None else list(range(self.cp))
+        self.backend = backend
+        self.comm = comm
+
+    # -- helpers -----------------------------------------------------------
+    def _be(self):
+        if self.backend is None:
+            self.backend = HipBackend()
+        return self.backend
+
+    def _peers(self):
+        nxt = self.global_ranks[(self.rank + 1) % self.cp]
+        prv = self.global_ranks[(self.rank - 1) % self.cp]
+        return nxt, prv
+
+    def _comm(self, device):
+        if self.comm is None:
+            self.comm = TorchDistComm(self.group, device)
+        return self.comm
+
+    def step_rect(self, step: int, s_loc: int):
+        """(q_rect, k_rect, causal, shift) of ring step ``step`` on a rank holding ``s_loc`` rows."""
+        c = s_loc // 2
+        src = (self.rank - step) % self.cp
+        if not self.causal:
+            return (0, s_loc), (0, s_loc), False, 0
+        if step == 0:
+            return (0, s_loc), (0, s_loc), True, 0
+        if src < self.rank:
+            return (0, s_loc), (0, c), False, 0
+        return (c, c), (0, s_loc), False, 0
+
+    # -- forward -----------------------------------------------------------
+    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False):
+        """q [s, b, Hq*d], k/v [s, b, Hkv*d] (local zig-zag shard) -> out [s, b, Hq*d]."""
+        be = self._be()
+        s_loc, b, hq_d = q.shape
+        d = hq_d // n_heads
+        hkv = k.shape[2] // d
+        if scale is None:
+            scale = 1.0 / math.sqrt(d)
+        if self.causal and s_loc % 2:
+            raise ValueError("zig-zag ring attention needs an even local sequence length")
+        q3 = q.reshape(s_loc, b * n_heads, d)
+        kv = [torch.stack([k.reshape(s_loc, b * hkv, d), v.reshape(s_loc, b * hkv, d)]), None]
+        if self.cp > 1:
+            kv[1] = torch.empty_like(kv[0])
+        out_acc = torch.zeros((s_loc, b * n_heads, d), dtype=torch.float32, device=q.device)
+        lse_acc = torch.full((b * n_heads, s_loc), float("-inf"), dtype=torch.float32, device=q.device)
+        out_blk = torch.empty((s_loc, b * n_heads, d), dtype=q.dtype, device=q.device)
+        lse_blk = torch.empty_like(lse_acc)
+        side = self._comm(q.device)
+        nxt, prv = self._peers()
+        for step in range(self.cp):
+            cur, oth = kv[step % 2], kv[(step + 1) % 2]
+            handle = None
+            if step + 1 < self.cp:
+                handle = side.exchange([cur], [oth], nxt, prv)
+            qr, kr, causal, shift = self.step_rect(step, s_loc)
+            be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk)
+            be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1])
+            if handle is not None:
+                side.wait(handle)
+        out = be.finalize(out_acc).reshape(s_loc, b, hq_d)
+        if return_state:
+            return out, lse_acc
+        return out
+
+    # -- backward ----------------------------------------------------------
+    def backward(self, q, k, v, out, lse, dout, n_heads: int, scale: float | None = None):
+        """Gradients (dq, dk, dv) in the layouts/dtypes of q, k, v."""
+        be = self._be()
+        s_loc, b, hq_d = q.shape
+        d = hq_d // n_heads
+        hkv = k.shape[2] // d
+        if scale is None:
+            scale = 1.0 / math.sqrt(d)
+        q3 = q.reshape(s_loc, b * n_heads, d)
+        out3 = out.reshape(s_loc, b * n_heads, d)
+        dout3 = dout.reshape(s_loc, b * n_heads, d)
+        delta = be.delta(out3, dout3, lse)
+        kv = [torch.stack([k.reshape(s_loc, b * hkv, d), v.reshape(s_loc, b * hkv, d)]), None]
+        dkv = [torch.zeros((2, s_loc, b * hkv, d), dtype=torch.float32, device=q.device), None]
+        if self.cp > 1:
+            kv[1] = torch.empty_like(kv[0])
+            dkv[1] = torch.empty_like(dkv[0])
+        dq_acc = torch.zeros((s_loc, b * n_heads, d), dtype=torch.float32, device=q.device)
+        side = self._comm(q.device)
+        nxt, prv = self._peers()
+        for step in range(self.cp):
+            cur, oth = kv[step % 2], kv[(step + 1) % 2]
+            dcur, doth = dkv[step % 2], dkv[(step + 1) % 2]
+            handle = None
+            if step + 1 < self.cp:
+                handle = side.exchange([cur], [oth], nxt, prv)   # K/V travels ahead of the math
+            qr, kr, causal, shift = self.step_rect(step, s_loc)
+            be.block_bwd(q3, cur[0], cur[1], out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dcur[0], dcur[1])
+            if handle is not None:
+                side.wait(handle)
+            if self.cp > 1:
+                # the accumulator follows its K/V block; after the last step one more hop returns it home
+                h2 = side.exchange([dcur], [doth], nxt, prv)
+                side.wait(h2)
+        final = dkv[self.cp % 2] if self.cp > 1 else dkv[0]
+        dq = be.cast(dq_acc, q.dtype).reshape(s_loc, b, hq_d)
+        dk = be.cast(final[0], k.dtype).reshape(s_loc, b, hkv * d)
+        dv = be.cast(final[1], v.dtype).reshape(s_loc, b, hkv * d)
+        return dq, dk, dv
+
+
+class _RingAttnFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, engine, n_heads, scale):
+        out, lse = engine.forward(q, k, v, n_heads, scale, return_state=True)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.engine, ctx.n_heads, ctx.scale = engine, n_heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = ctx.engine.backward(q, k, v, out, lse, dout.contiguous(), ctx.n_heads, ctx.scale)
+        return dq, dk, dv, None, None, None
+
+
+_engines: dict = {}
+
+
+def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask=None, dropout_p=0.,
+                              actual_seq_qlen=None, actual_seq_kvlen=None):
+    """Drop-in for mindspeed.core.context_parallel.ring_context_parallel.ringattn_context_parallel
+    as called at dot_product_attention.py:70-71.
+
+    ``cp_para`` keys read: causal, cp_group, cp_size, rank, cp_global_ranks (the double-ring
+    window keys cp_inner_ranks / cp_outer_ranks / ... are accepted and must describe a single
+    ring: one 8-GPU node has no inter-node window), pse must be None."""
+    if dropout_p not in (0, 0.0):
+        raise NotImplementedError("attention dropout is not supported on the ring path (the shipped scripts use 0)")
+    if cp_para.get("pse") is not None:
+        raise NotImplementedError("pse / alibi is not supported on the ring path")
+    if actual_seq_qlen is not None and cp_para.get("causal", True) is False:
+        raise NotImplementedError("packed variable-length segments with context parallelism are not supported")
+    cp_size = int(cp_para["cp_size"])
+    rank = int(cp_para["rank"])
+    group = cp_para.get("cp_group")
+    ranks = cp_para.get("cp_global_ranks")
+    key = (id(group), cp_size, rank, bool(cp_para.get("causal", True)), tuple(ranks) if ranks is not None else None)
+    eng = _engines.get(key)
+    if eng is None:
+        eng = RingAttention(group, cp_size, rank, causal=bool(cp_para.get("causal", True)), global_ranks=ranks)
+        _engines[key] = eng
+    d = q.shape[-1] // n
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
+    return _RingAttnFunction.apply(q, k, v, eng, n, float(scale))

@@ -1,0 +1,94 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/lvattn.h
+declares, and its pure-host entry points (block builders, argument validation)
+behave.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lvattn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lv(?:attn)?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from long_vita_amd import _lib
+    handle = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+    assert handle.lvattn_abi_version() == 1
+
+
+def _blocks(cu, causal, backward=False):
+    from long_vita_amd import ops
+    return ops.build_blocks_host(cu, causal, backward)
+
+
+def test_forward_blocks_cover_segments_exactly():
+    cu = [0, 100, 356, 357, 700, 1290, 1290, 5000]
+    d = _blocks(cu, True)
+    seen = np.zeros(cu[-1], dtype=int)
+    for q0, qn, k0, kl, sh, *_ in d.tolist():
+        seen[q0:q0 + qn] += 1
+        seg = max(i for i in range(len(cu) - 1) if cu[i] <= q0 and cu[i + 1] > q0)
+        assert k0 == cu[seg] and sh == q0 - k0
+        assert kl == min(q0 + qn, cu[seg + 1]) - k0          # causal: keys up to the block's last row
+        assert 1 <= qn <= 256
+    assert (seen == 1).all()
+    work = [qn * kl for _, qn, _, kl, *_ in d.tolist()]
+    assert work == sorted(work, reverse=True)                # heaviest first
+    dn = _blocks(cu, False)
+    for q0, qn, k0, kl, sh, *_ in dn.tolist():
+        seg = max(i for i in range(len(cu) - 1) if cu[i] <= q0 and cu[i + 1] > q0)
+        assert (k0, kl) == (cu[seg], cu[seg + 1] - cu[seg])
+
+
+def test_backward_blocks_visibility_rule():
+    cu = [0, 130, 700]
+    d = _blocks(cu, True, backward=True)
+    seen = np.zeros(cu[-1], dtype=int)
+    for k0, kn, q0, ql, sh, *_ in d.tolist():
+        seen[k0:k0 + kn] += 1
+        seg = 0 if k0 < 130 else 1
+        assert q0 + ql == cu[seg + 1]
+        assert q0 <= k0 and (k0 - q0) < 32 and (q0 - cu[seg]) % 32 == 0
+        # key k0+j visible to query q0+i iff j <= i + sh  <=>  k0+j <= q0+i
+        assert sh == q0 - k0
+    assert (seen == 1).all()
+
+
+def test_rect_blocks_and_errors():
+    from long_vita_amd import ops, _lib
+    d = ops.build_rect_blocks_host(512, 512, 0, 1024, False, 0)
+    assert d[:, 0].tolist() == [512, 768] and (d[:, 3] == 1024).all()
+    d = ops.build_rect_blocks_host(0, 600, 0, 600, True, 0)
+    assert sorted(d[:, 0].tolist()) == [0, 256, 512]
+    with pytest.raises(_lib.LvAttnError):
+        ops.build_blocks_host([0, 10, 5], True)
+    # argument validation happens before any HIP call
+    L = _lib.lib()
+    rc = L.lvattn_fwd(None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1.0, 1, None)
+    assert rc == -1 and b"null" in L.lvattn_last_error()
+    buf = C.create_string_buffer(64)
+    p = C.addressof(buf) + (16 - C.addressof(buf) % 16)
+    rc = L.lvattn_fwd(p, p, p, p, p, p, 1, 1, 1, 3, 2, 128, 128, 128, 128, 128, 128, 128, 128, 128, 1, 1.0, 1, None)
+    assert rc == -1 and b"multiple" in L.lvattn_last_error()
+    rc = L.lvattn_fwd(p, p, p, p, p, p, 1, 1, 1, 2, 2, 96, 128, 128, 128, 128, 128, 128, 128, 128, 1, 1.0, 1, None)
+    assert rc == -1 and b"head dim" in L.lvattn_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from long_vita_amd import ops, _lib
+    q = torch.zeros(4, 1, 128, dtype=torch.bfloat16)
+    with pytest.raises(_lib.LvAttnError):
+        ops.varlen_attention(q, q, q, [0, 4])

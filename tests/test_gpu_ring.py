@@ -1,0 +1,52 @@
+"""Ring attention with the HIP backend on one GPU: CP virtual ranks run as threads
+of this process over a loopback transport (the box has a single MI355X; the RCCL
+transport itself is exercised by bench.py --gpus N on a multi-GPU node)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention_ref as A
+from tests.ring_helpers import LoopbackComm, LoopbackFabric, run_virtual_ranks, unzigzag, zigzag_local
+
+REL_TOL = 2e-2
+LSE_TOL = 1e-3
+
+
+def rel(got, ref):
+    g = got.detach().float().cpu().numpy().astype(np.float64)
+    return float(np.abs(g - ref).max() / np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cp,S", [(2, 1024), (4, 2048), (8, 4096)])
+def test_ring_hip_backend_matches_full_causal(cp, S):
+    from long_vita_amd.ring_context_parallel import RingAttention
+    Hq, Hkv, D = 10, 2, 128
+    g = torch.Generator().manual_seed(cp)
+    q = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    ref_o, ref_lse = A.varlen_attention(q, k, v, [0, S], scale)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, [0, S], scale)
+    fabric = LoopbackFabric(cp)
+    dev = torch.device("cuda", 0)
+
+    def body(r):
+        torch.cuda.set_device(0)
+        eng = RingAttention(None, cp, r, causal=True, comm=LoopbackComm(fabric, r))
+        ql, kl, vl, dl = (zigzag_local(x, cp, r).reshape(S // cp, 1, -1).to(dev) for x in (q, k, v, do))
+        out, lse = eng.forward(ql, kl, vl, Hq, scale, return_state=True)
+        dq, dk, dv = eng.backward(ql, kl, vl, out, lse, dl, Hq, scale)
+        torch.cuda.synchronize()
+        return out[:, 0].cpu(), lse.cpu(), dq[:, 0].cpu(), dk[:, 0].cpu(), dv[:, 0].cpu()
+    res = run_virtual_ranks(cp, body)
+    out = unzigzag([r[0] for r in res], cp).reshape(S, Hq, D)
+    assert rel(out, ref_o) <= REL_TOL
+    lse = unzigzag([r[1].t() for r in res], cp).t()
+    assert np.abs(lse.numpy() - ref_lse).max() <= LSE_TOL
+    for idx, ref, H in ((2, rdq, Hq), (3, rdk, Hkv), (4, rdv, Hkv)):
+        got = unzigzag([r[idx] for r in res], cp).reshape(S, H, D)
+        assert rel(got, ref) <= REL_TOL, idx
