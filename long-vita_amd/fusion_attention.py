@@ -1,0 +1,101 @@
+"""``npu_fusion_attention``-shaped entry point backed by the gfx950 kernels.
+
+The reference calls ``torch_npu.npu_fusion_attention`` at
+lcvlm_modellink/core/transformer/dot_product_attention.py:314-325 (ViT: SBH, no
+mask, sparse_mode 0), :352-365 (LLM: TND, causal template mask, sparse_mode 2,
+actual_seq_qlen/kvlen) and :454-467 (generic SBH / BNSD / TND).  This function takes
+the same arguments and returns a tuple whose element 0 is the attention output in
+the input layout; elements 1 and 2 are (softmax_max, softmax_sum) in the
+decomposition max = log-sum-exp, sum = 1 (lse = max + ln(sum) as in the NPU op).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+def _is_causal(atten_mask, sparse_mode, pre_tockens, next_tockens):
+    if atten_mask is None:
+        if sparse_mode == 0:
+            return False
+        raise ValueError(f"sparse_mode={sparse_mode} needs an atten_mask")
+    if sparse_mode in (2, 3, 4):
+        # 2 = left-up causal, 3 = right-down causal (identical when q and kv lengths agree),
+        # 4 = band with pre/next tokens; the reference only uses the causal band (next_tockens = 0).
+        if sparse_mode == 4 and next_tockens not in (0,):
+            raise NotImplementedError("band attention with next_tockens != 0 is not supported")
+        return True
+    if sparse_mode in (0, 1):
+        if atten_mask is True:
+            return True
+        m = atten_mask
+        if m.dim() >= 2 and m.shape[-1] == m.shape[-2]:
+            n = m.shape[-1]
+            tri = torch.triu(torch.ones(n, n, dtype=torch.bool, device=m.device), 1)
+            if bool((m.reshape(-1, n, n)[0].bool() == tri).all()):
+                return True
+            if not bool(m.any()):
+                return False
+        raise NotImplementedError("only causal or empty masks are supported")
+    raise NotImplementedError(f"sparse_mode={sparse_mode}")
+
+
+def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, padding_mask=None, atten_mask=None,
+                         scale=1.0, keep_prob=1.0, pre_tockens=2147483647, next_tockens=2147483647, inner_precise=0,
+                         prefix=None, actual_seq_qlen=None, actual_seq_kvlen=None, sparse_mode=0, gen_mask_parallel=True,
+                         sync=False):
+    if pse is not None:
+        raise NotImplementedError("pse (alibi) is not supported")
+    if padding_mask is not None or prefix is not None:
+        raise NotImplementedError("padding_mask / prefix are not supported")
+    if keep_prob != 1.0:
+        raise NotImplementedError("attention dropout is not supported (the shipped scripts use 0)")
+    causal = _is_causal(atten_mask, sparse_mode, pre_tockens, next_tockens)
+
+    if input_layout == "TND":
+        if actual_seq_qlen is None:
+            raise ValueError("TND layout needs actual_seq_qlen")
+        if actual_seq_kvlen is not None and list(actual_seq_kvlen) != list(actual_seq_qlen):
+            raise NotImplementedError("different q / kv segmentations are not supported")
+        cu = ops.cu_seqlens_from_actual_seq_len(actual_seq_qlen)
+        out, lse = ops.varlen_attention(query, key, value, cu, scale, causal)
+        return out, lse, torch.ones_like(lse)
+
+    if input_layout == "SBH":
+        s, b, hd = query.shape
+        d = hd // head_num
+        hkv = key.shape[2] // d
+        # [s, b, h*d] is [s rows, b*h heads, d] with row stride b*h*d: no copy, batch folds into heads
+        q3 = query.reshape(s, b * head_num, d)
+        k3 = key.reshape(key.shape[0], b * hkv, d)
+        v3 = value.reshape(value.shape[0], b * hkv, d)
+        if k3.shape[0] != s:
+            raise NotImplementedError("q and kv lengths differ")
+        out, lse = ops.varlen_attention(q3, k3, v3, [0, s], scale, causal)
+        return out.reshape(s, b, hd), lse, torch.ones_like(lse)
+
+    if input_layout in ("BSH", "BSND", "BNSD"):
+        if input_layout == "BNSD":
+            b, n, s, d = query.shape
+            to_t = lambda x: x.permute(0, 2, 1, 3).reshape(b * s, x.shape[1], d)
+        elif input_layout == "BSND":
+            b, s, n, d = query.shape
+            to_t = lambda x: x.reshape(b * s, x.shape[2], d)
+        else:
+            b, s, hd = query.shape
+            d = hd // head_num
+            to_t = lambda x: x.reshape(b * s, x.shape[2] // d, d)
+        cu = [i * s for i in range(b + 1)]
+        out, lse = ops.varlen_attention(to_t(query), to_t(key), to_t(value), cu, scale, causal)
+        if input_layout == "BNSD":
+            out = out.reshape(b, s, -1, d).permute(0, 2, 1, 3)
+        elif input_layout == "BSND":
+            out = out.reshape(b, s, -1, d)
+        else:
+            out = out.reshape(b, s, -1)
+        return out, lse, torch.ones_like(lse)
+
+    raise ValueError(f"unknown input_layout {input_layout!r}")

@@ -1,0 +1,68 @@
+"""Vision-token compression and the scatter of visual features into the LLM input.
+
+  pixel_shuffle / vit_output_to_llm_tokens   lcvlm_modellink/pretrain_lcvlm.py:463-470, 546-556
+  scatter_external_features                  lcvlm_modellink/core/models/common/embeddings/
+                                             language_model_embedding.py:114-134
+  vit_attention                              the InternViT-300M core attention call
+                                             (dot_product_attention.py:309-325; 24 layers of
+                                             16 heads x 64, 1025 tokens: pretrain_lcvlm.py:191-213)
+All three run as HIP kernels (pure 16-byte moves for the first two); there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .fusion_attention import npu_fusion_attention
+
+INTERN_VIT_300M = dict(num_layers=24, hidden_size=1024, num_attention_heads=16, kv_channels=64,
+                       seq_length=1025, patch_dim=14, img_h=448, img_w=448, image_token_length=256)
+
+
+def pixel_shuffle(x: torch.Tensor, scale_factor: float = 0.5) -> torch.Tensor:
+    """[N, W, H, C] -> [N, W/2, H/2, 4C] (only scale_factor 0.5, the value every script uses)."""
+    if scale_factor != 0.5:
+        raise NotImplementedError("only scale_factor=0.5 is built")
+    n, w, h, c = x.shape
+    if w != h:
+        raise ValueError("pixel_shuffle expects a square token grid")
+    out = ops.pixel_shuffle_tokens(x.reshape(n, w * h, c), skip=0)
+    return out.reshape(n, w // 2, h // 2, 4 * c)
+
+
+def vit_output_to_llm_tokens(vit_output: torch.Tensor, add_class_token: bool = True) -> torch.Tensor:
+    """[N, 1025, C] -> [N, 256, 4C]: class-token drop + reshape + pixel_shuffle(0.5) + flatten,
+    fused into one pass over the data."""
+    return ops.pixel_shuffle_tokens(vit_output, skip=1 if add_class_token else 0)
+
+
+def scatter_external_features(word_embeddings: torch.Tensor, external_feature_dict: dict) -> torch.Tensor:
+    """In-place scatter into ``word_embeddings`` [b, s, h] (bf16, contiguous)."""
+    features = external_feature_dict["features"]
+    b, s, h = word_embeddings.shape
+    if "indices" in external_feature_dict:
+        ind_b, ind_s = external_feature_dict["indices"].unbind(dim=0)
+        dst = (ind_b.reshape(-1) * s + ind_s.reshape(-1))
+        ops.scatter_rows_(word_embeddings.view(b * s, h), dst, features.reshape(-1, features.shape[-1]))
+    elif "pre_len" in external_feature_dict:
+        pre = int(external_feature_dict["pre_len"])
+        n = features.shape[1]
+        dst = (torch.arange(b, device=features.device)[:, None] * s + torch.arange(pre, pre + n, device=features.device)[None])
+        ops.scatter_rows_(word_embeddings.view(b * s, h), dst.reshape(-1), features.reshape(-1, h))
+    elif "src_indices" in external_feature_dict and "tgt_indices" in external_feature_dict:
+        src_b, src_s = external_feature_dict["src_indices"]
+        tgt_b, tgt_s = external_feature_dict["tgt_indices"]
+        n_tok = features.shape[1]
+        ops.scatter_rows_(word_embeddings.view(b * s, h), tgt_b * s + tgt_s, features.reshape(-1, features.shape[-1]),
+                          src_b * n_tok + src_s)
+    return word_embeddings
+
+
+def vit_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, scale: float | None = None) -> torch.Tensor:
+    """Full (bidirectional) multi-head attention in the ViT layout: q/k/v [s, b, h, d] -> [s, b, h*d]."""
+    s, b, h, d = query.shape
+    scale = 1.0 / math.sqrt(d) if scale is None else scale
+    q, k, v = (x.reshape(s, b, h * d) for x in (query, key, value))
+    return npu_fusion_attention(q, k, v, h, "SBH", atten_mask=None, scale=scale, sparse_mode=0)[0]

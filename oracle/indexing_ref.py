@@ -87,15 +87,16 @@ def pack_samples(sample_lengths, image_positions, max_len: int, shift_token: boo
     array [n_img_i, n_tok] of visual-token positions inside sample i (may be
     empty).  Returns actual_seq_len (cumulative END offsets, last := max_len),
     position_ids (restart per sample, padded with the last id), and
-    image_indices [2, n_img, n_tok] with row 1 shifted by the running length
-    (:147) and row 0 zero."""
+    image_indices [2, n_img, n_tok] with row 0 zero and row 1 shifted by the running
+    length (:147) -- but, exactly as the reference does, ONLY when the pack already
+    holds images: the first image-bearing sample is stored unshifted (:151-153)."""
     actual = []
     pos_ids = []
     img = []
     total = 0
     for L, ip in zip(sample_lengths, image_positions):
         if ip is not None and len(ip) > 0:
-            img.append(np.asarray(ip, dtype=np.int64) + total)        # :147
+            img.append(np.asarray(ip, dtype=np.int64) + (total if img else 0))   # :142-153
         pos_ids += list(range(L))                                       # :162
         actual.append(total + L)                                        # :166
         total += L

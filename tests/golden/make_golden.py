@@ -21,6 +21,7 @@ Fixtures written:
                        (legacy/data/data_samplers.py), pixel_shuffle
                        (pretrain_lcvlm.py), get_pos_emb_on_this_cp_rank
                        (rotary_pos_embedding.py)
+  packing.npz          Qwen2Dataset.add_ret / process_ret (cognitron_vl/data/dataset_qwen2.py)
 """
 from __future__ import annotations
 
@@ -37,7 +38,7 @@ import torch
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-STUB_ROOTS = ("megatron", "mindspeed", "torch_npu", "modellink", "apex", "amp_C", "cognitron_vl")
+STUB_ROOTS = ("megatron", "mindspeed", "torch_npu", "modellink", "apex", "amp_C", "cognitron_vl", "cv2", "decord", "natsort", "datasets")
 
 
 class _StubMeta(type):
@@ -269,7 +270,48 @@ def gen_indexing():
     print("indexing.npz:", len(out), "arrays")
 
 
+def gen_packing():
+    """Qwen2Dataset.add_ret / process_ret (cognitron_vl/data/dataset_qwen2.py:132-254) run
+    unbound on a namespace standing in for the dataset object.  The module is loaded by
+    file path under its own dotted name so that its relative imports hit the shim."""
+    import importlib.util
+    path = os.path.join(REF, "cognitron_vl", "data", "dataset_qwen2.py")
+    spec = importlib.util.spec_from_file_location("cognitron_vl.data.dataset_qwen2", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    DS = mod.Qwen2Dataset
+    out = {}
+
+    def run(case, samples, max_len, reset, shift_token=False):
+        self = ns(ret={"src": {"tokens": [], "labels": [], "actual_seq_len": [], "position_ids": []}},
+                  create_attention_mask=False, create_attention_mask_2d=False, create_position_ids=True,
+                  create_loss_mask=True, reset_position_ids=reset, reset_attention_mask=reset, shift_token=shift_token,
+                  variable_length=False, max_len=max_len, tokenizer=ns(pad_token_id=0))
+        for i, (L, img) in enumerate(samples):
+            ret = {"input_ids": list(range(1000 * i, 1000 * i + L)), "labels": list(range(L)), "images": []}
+            if img is not None:
+                pos = torch.tensor(img, dtype=torch.int64)
+                ret["image_indices"] = torch.stack([torch.zeros_like(pos), pos], dim=0)
+                ret["images"] = torch.zeros(pos.shape[0], 3)
+            DS.add_ret(self, ret, "src")
+        to_ret = DS.process_ret(self, self.ret["src"])
+        out[f"{case}.lengths"] = np.asarray([L for L, _ in samples])
+        for k in ("tokens", "labels", "position_ids", "actual_seq_len", "loss_mask", "image_indices"):
+            if k in to_ret:
+                out[f"{case}.{k}"] = to_ret[k].numpy() if hasattr(to_ret[k], "numpy") else np.asarray(to_ret[k])
+    img_a = [[2, 3, 4, 5], [8, 9, 10, 11]]
+    img_b = [[1, 2, 3, 4]]
+    run("pad", [(15, img_a), (9, None), (6, img_b)], 40, True)
+    run("trunc", [(15, None), (9, img_b), (20, None)], 32, True)
+    run("late_image", [(10, None), (12, img_b), (8, img_a)], 32, True)
+    run("shift", [(15, img_a), (9, None)], 32, True, shift_token=True)
+    run("noreset", [(15, img_a), (9, None)], 32, False)
+    np.savez_compressed(os.path.join(HERE, "packing.npz"), **out)
+    print("packing.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     install_shim()
     gen_eager_attention()
     gen_indexing()
+    gen_packing()

@@ -1,0 +1,157 @@
+"""Bit-exact GPU tests of the data-movement kernels (pixel shuffle, feature scatter,
+zig-zag row gather) and of the core-attention dispatch mirror, against the oracle and
+the fixtures produced by the reference's own code."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention_ref as A
+from oracle import indexing_ref as I
+
+
+def bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().view(torch.int16).numpy()
+
+
+def test_pixel_shuffle_matches_reference_fixture(golden_dir):
+    from long_vita_amd import vision
+    g = np.load(os.path.join(golden_dir, "indexing.npz"))
+    # the fixture's values (0..2047) are not all bf16-exact: send value % 256 and value // 256 separately
+    xin = g["ps.small.in"].astype(np.int64)
+    lo_s = vision.pixel_shuffle(torch.from_numpy((xin % 256).astype(np.float32)).to(torch.bfloat16).cuda(), 0.5)
+    hi_s = vision.pixel_shuffle(torch.from_numpy((xin // 256).astype(np.float32)).to(torch.bfloat16).cuda(), 0.5)
+    np.testing.assert_array_equal((lo_s.float() + 256 * hi_s.float()).cpu().numpy(), g["ps.small.out"])
+    # full-size permutation [1,32,32,1024] -> [1,16,16,4096]: encode the flat source index in 2 bf16-exact planes
+    idx = np.arange(32 * 32 * 1024, dtype=np.int64).reshape(1, 32, 32, 1024)
+    lo = torch.from_numpy((idx % 256).astype(np.float32)).to(torch.bfloat16).cuda()
+    hi = torch.from_numpy((idx // 256 % 256).astype(np.float32)).to(torch.bfloat16).cuda()
+    top = torch.from_numpy((idx // 65536).astype(np.float32)).to(torch.bfloat16).cuda()
+    rec = (vision.pixel_shuffle(lo).float() + 256 * vision.pixel_shuffle(hi).float()
+           + 65536 * vision.pixel_shuffle(top).float()).cpu().numpy().astype(np.int64)
+    np.testing.assert_array_equal(rec, g["ps.full.index_map"].astype(np.int64))
+
+
+def test_vit_output_to_llm_tokens_bit_exact():
+    from long_vita_amd import vision
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 1025, 1024, generator=g).to(torch.bfloat16)
+    ref = I.vit_tokens_to_llm_tokens(x.view(torch.int16).numpy())       # pure movement: compare bit patterns
+    got = vision.vit_output_to_llm_tokens(x.cuda())
+    assert got.shape == (5, 256, 4096)
+    np.testing.assert_array_equal(bf16_bits(got), ref)
+
+
+def test_scatter_features_bit_exact(golden_dir):
+    from long_vita_amd import vision
+    g = torch.Generator().manual_seed(1)
+    b, s, h, n_img, n_tok = 2, 600, 256, 3, 64
+    emb = torch.randn(b, s, h, generator=g).to(torch.bfloat16)
+    feats = torch.randn(n_img, n_tok, h, generator=g).to(torch.bfloat16)
+    starts = [5, 300, 100]
+    ind_s = torch.stack([torch.arange(st, st + n_tok) for st in starts])
+    ind_b = torch.tensor([0, 0, 1])[:, None].repeat(1, n_tok)
+    indices = torch.stack([ind_b, ind_s])
+    ref = I.scatter_features(emb.view(torch.int16).numpy(), feats.view(torch.int16).numpy(), indices=indices.numpy())
+    got = vision.scatter_external_features(emb.clone().cuda(), {"features": feats.cuda(), "indices": indices.cuda()})
+    np.testing.assert_array_equal(bf16_bits(got), ref)
+    # src / tgt form, as produced by the CP partition
+    sel, src, tgt = I.cp_image_remap(indices.numpy(), s + 40, 4, 1)   # seq 640, CP 4
+    emb2 = torch.randn(b, (s + 40) // 4, h, generator=g).to(torch.bfloat16)
+    fsel = feats[torch.from_numpy(sel)]
+    ref2 = I.scatter_features(emb2.view(torch.int16).numpy(), fsel.view(torch.int16).numpy(), src_indices=src, tgt_indices=tgt)
+    got2 = vision.scatter_external_features(emb2.clone().cuda(), {"features": fsel.cuda(), "src_indices": torch.from_numpy(src).cuda(),
+                                                                  "tgt_indices": torch.from_numpy(tgt).cuda()})
+    np.testing.assert_array_equal(bf16_bits(got2), ref2)
+    # no indices: nothing moves
+    got3 = vision.scatter_external_features(emb.clone().cuda(), {"features": feats.cuda()})
+    np.testing.assert_array_equal(bf16_bits(got3), emb.view(torch.int16).numpy())
+
+
+def test_zigzag_gather_on_gpu_bit_exact():
+    from long_vita_amd import cp_partition as P
+    table = torch.arange(4096 * 128, dtype=torch.float32).reshape(4096, 1, 1, 128)
+    for cp in (2, 8):
+        for r in (0, cp - 1):
+            got = P.get_pos_emb_on_this_cp_rank(table.cuda(), 0, cp, r)
+            np.testing.assert_array_equal(got.cpu().numpy(), I.zigzag_slice(table.numpy(), cp, r, 0))
+    pos = torch.randint(0, 4096, (300, 2))
+    got = P.gather_rotary_by_position_ids(table.cuda(), pos.cuda())
+    np.testing.assert_array_equal(got.cpu().numpy(), I.rope_position_gather(table.numpy(), pos.numpy()))
+    odd = torch.arange(37 * 3, dtype=torch.int32).reshape(37, 3).cuda()     # 12-byte rows: 4-byte path
+    idx = torch.tensor([5, 0, 36, 5]).cuda()
+    from long_vita_amd import ops
+    assert torch.equal(ops.gather_rows(odd, idx).cpu(), odd.cpu()[idx.cpu()])
+
+
+def _self(d):
+    return types.SimpleNamespace(hidden_size_per_attention_head=d, scale_mask_softmax=types.SimpleNamespace(scale=None),
+                                 softmax_scale=None, attention_dropout=types.SimpleNamespace(p=0.0), alibi=None,
+                                 pse=None, pse_type=None)
+
+
+def _rel(got, ref):
+    g = got.detach().float().cpu().numpy().astype(np.float64)
+    return float(np.abs(g - ref).max() / np.abs(ref).max())
+
+
+def test_flash_attention_forward_branches_match_oracle():
+    """cfg1-shaped plumbing: 8192 packed tokens with the first segment one 448px image (258
+    tokens), Qwen2 head ratio, through the same entry point the reference patches in."""
+    from long_vita_amd import state
+    from long_vita_amd.core_attention import flash_attention_forward
+    g = torch.Generator().manual_seed(2)
+    s, b, hq, hkv, d = 8192, 1, 10, 2, 128
+    actual = [258, 1290, 3000, 5120, 8192]
+    q = torch.randn(s, b, hq, d, generator=g).to(torch.bfloat16)
+    k = torch.randn(s, b, hkv, d, generator=g).to(torch.bfloat16)
+    v = torch.randn(s, b, hkv, d, generator=g).to(torch.bfloat16)
+    # LLM varlen branch
+    state.set_args(state.make_args(reset_attention_mask=True, reset_position_ids=True))
+    state.set_actual_seq_len(actual)
+    out = flash_attention_forward(_self(d), q.cuda(), k.cuda(), v.cuda(), None, None, None)
+    assert out.shape == (s, b, hq * d)
+    ref, _ = A.varlen_attention(q[:, 0, :4], k[:, 0, :1], v[:, 0, :1], [0] + actual, A.default_scale(d))  # heads 0-3 of group 0
+    assert _rel(out.reshape(s, hq, d)[:, :4], ref) <= 2e-2
+    # generic causal branch (no reset): one causal block over the whole row
+    state.set_args(state.make_args())
+    state.set_actual_seq_len(None)
+    out2 = flash_attention_forward(_self(d), q[:2048].cuda(), k[:2048].cuda(), v[:2048].cuda(), None, None, None)
+    ref2, _ = A.varlen_attention(q[:2048, 0, :2], k[:2048, 0, :1], v[:2048, 0, :1], [0, 2048], A.default_scale(d))
+    assert _rel(out2.reshape(2048, hq, d)[:, :2], ref2) <= 2e-2
+    # ViT branch: chosen by the sequence length, bidirectional, b images
+    sv, bv, hv, dv = 1025, 3, 4, 64
+    qv, kv, vv = (torch.randn(sv, bv, hv, dv, generator=g).to(torch.bfloat16) for _ in range(3))
+    out3 = flash_attention_forward(_self(dv), qv.cuda(), kv.cuda(), vv.cuda(), None, None, None)
+    assert out3.shape == (sv, bv, hv * dv)
+    for bi in range(bv):
+        ref3, _ = A.varlen_attention(qv[:, bi], kv[:, bi], vv[:, bi], [0, sv], A.default_scale(dv), causal=False)
+        assert _rel(out3[:, bi].reshape(sv, hv, dv), ref3) <= 2e-2
+
+
+def test_fusion_attention_layouts_agree():
+    from long_vita_amd.fusion_attention import npu_fusion_attention
+    g = torch.Generator().manual_seed(3)
+    b, s, n, nkv, d = 2, 300, 4, 2, 128
+    q = torch.randn(b, s, n, d, generator=g).to(torch.bfloat16).cuda()
+    k = torch.randn(b, s, nkv, d, generator=g).to(torch.bfloat16).cuda()
+    v = torch.randn(b, s, nkv, d, generator=g).to(torch.bfloat16).cuda()
+    sc = A.default_scale(d)
+    o_bsnd = npu_fusion_attention(q, k, v, n, "BSND", atten_mask=True, scale=sc, sparse_mode=2)[0]
+    o_bnsd = npu_fusion_attention(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), n, "BNSD",
+                                  atten_mask=True, scale=sc, sparse_mode=2)[0]
+    o_bsh = npu_fusion_attention(q.reshape(b, s, -1), k.reshape(b, s, -1), v.reshape(b, s, -1), n, "BSH",
+                                 atten_mask=True, scale=sc, sparse_mode=2)[0]
+    o_sbh = npu_fusion_attention(q.permute(1, 0, 2, 3).reshape(s, b, -1), k.permute(1, 0, 2, 3).reshape(s, b, -1),
+                                 v.permute(1, 0, 2, 3).reshape(s, b, -1), n, "SBH", atten_mask=True, scale=sc, sparse_mode=2)[0]
+    assert torch.equal(o_bsnd, o_bnsd.permute(0, 2, 1, 3))
+    assert torch.equal(o_bsnd.reshape(b, s, -1), o_bsh)
+    assert torch.equal(o_bsnd.reshape(b, s, -1), o_sbh.permute(1, 0, 2))
+    ref, _ = A.varlen_attention(q[1].cpu(), k[1].cpu(), v[1].cpu(), [0, s], sc)
+    assert _rel(o_bsnd[1], ref) <= 2e-2
+    with pytest.raises(NotImplementedError):
+        npu_fusion_attention(q, k, v, n, "BSND", keep_prob=0.9)

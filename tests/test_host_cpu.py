@@ -1,0 +1,140 @@
+"""Host-side mirrors of the reference's partition / packing code, bit-exact against
+fixtures produced by the reference's own functions.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import indexing_ref as I
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _set_state(S, cp, r):
+    from long_vita_amd import state
+    state.set_args(state.make_args(seq_length=S, context_parallel_size=cp))
+    state.mpu.initialize(None, cp, r)
+
+
+def test_index_of_a_in_b(golden_dir):
+    from long_vita_amd.cp_partition import index_of_a_in_b
+    g = _g(golden_dir, "indexing.npz")
+    got = index_of_a_in_b(torch.from_numpy(g["ioab.a"]), torch.from_numpy(g["ioab.b"]))
+    np.testing.assert_array_equal(got.numpy(), g["ioab.out"])
+
+
+@pytest.mark.parametrize("S,cp", [(64, 2), (256, 4), (1024, 8)])
+def test_cp_batch_partition_matches_reference(golden_dir, S, cp):
+    from long_vita_amd import cp_partition as P
+    g = _g(golden_dir, "indexing.npz")
+    tag = f"zz.S{S}.cp{cp}"
+    gathered = []
+    for r in range(cp):
+        _set_state(S, cp, r)
+        batch = {"tokens": torch.from_numpy(g[f"{tag}.tokens"]).clone(),
+                 "position_ids": torch.arange(S).repeat(2, 1), "attention_mask": None,
+                 "external_images": torch.from_numpy(g[f"{tag}.images"]).clone(),
+                 "external_indices": torch.from_numpy(g[f"{tag}.external_indices"]).clone()}
+        out = P.get_batch_on_this_cp_rank(batch)
+        np.testing.assert_array_equal(out["tokens"].numpy(), g[f"{tag}.r{r}.tokens"])
+        np.testing.assert_array_equal(out["position_ids"].numpy(), g[f"{tag}.r{r}.position_ids"])
+        np.testing.assert_array_equal(out["external_images"].numpy(), g[f"{tag}.r{r}.images"])
+        assert "external_indices" not in out
+        if f"{tag}.r{r}.src" in g.files:
+            np.testing.assert_array_equal(out["external_src_indices"].numpy(), g[f"{tag}.r{r}.src"])
+            np.testing.assert_array_equal(out["external_tgt_indices"].numpy(), g[f"{tag}.r{r}.tgt"])
+        else:
+            assert "external_src_indices" not in out
+        gathered.append(out["tokens"])
+    # sync_output's reordering restores the global order
+    np.testing.assert_array_equal(P.unzigzag_gathered(gathered, cp, 1).numpy(), g[f"{tag}.tokens"])
+
+
+def test_rope_slice_and_gather(golden_dir):
+    from long_vita_amd import cp_partition as P
+    g = _g(golden_dir, "indexing.npz")
+    emb = torch.from_numpy(g["rope.in"])
+    for cp in (2, 4):
+        for r in range(cp):
+            got = P.get_pos_emb_on_this_cp_rank(emb, 0, cp, r)
+            np.testing.assert_array_equal(got.numpy(), g[f"rope.cp{cp}.r{r}"])
+    pos = torch.tensor([[0, 0], [1, 1], [2, 0], [0, 1]])
+    got = P.gather_rotary_by_position_ids(emb, pos)
+    np.testing.assert_array_equal(got.numpy(), I.rope_position_gather(g["rope.in"], pos.numpy()))
+
+
+def test_packing_matches_reference(golden_dir):
+    from long_vita_amd.packing import PackedSample
+    g = _g(golden_dir, "packing.npz")
+    img_a = [[2, 3, 4, 5], [8, 9, 10, 11]]
+    img_b = [[1, 2, 3, 4]]
+    cases = {"pad": ([(15, img_a), (9, None), (6, img_b)], 40, True, False),
+             "trunc": ([(15, None), (9, img_b), (20, None)], 32, True, False),
+             "late_image": ([(10, None), (12, img_b), (8, img_a)], 32, True, False),
+             "shift": ([(15, img_a), (9, None)], 32, True, True),
+             "noreset": ([(15, img_a), (9, None)], 32, False, False)}
+    for name, (samples, max_len, reset, shift) in cases.items():
+        ps = PackedSample(max_len, 0, reset, reset, shift_token=shift)
+        for i, (L, img) in enumerate(samples):
+            ii = None
+            if img is not None:
+                pos = torch.tensor(img, dtype=torch.int64)
+                ii = torch.stack([torch.zeros_like(pos), pos])
+            ps.add(list(range(1000 * i, 1000 * i + L)), list(range(L)), ii)
+        out = ps.finalize()
+        for k in ("tokens", "labels", "position_ids", "actual_seq_len", "loss_mask", "image_indices"):
+            key = f"{name}.{k}"
+            if key in g.files:
+                np.testing.assert_array_equal(out[k].numpy(), g[key], err_msg=key)
+            else:
+                assert k not in out, key
+
+
+def test_collate_matches_reference(golden_dir):
+    from long_vita_amd.packing import collate_fn
+    g = _g(golden_dir, "indexing.npz")
+    rows = []
+    for i in range(3):
+        d = {"tokens": torch.arange(32) + 100 * i, "actual_seq_len": torch.from_numpy(g[f"collate.in_actual{i}"])}
+        if f"collate.in_img{i}" in g.files:
+            img = torch.from_numpy(g[f"collate.in_img{i}"]).clone()
+            d["image_indices"] = img
+            d["images"] = torch.full((img.shape[1], 3), float(i))
+        rows.append(d)
+    out = collate_fn(rows)
+    np.testing.assert_array_equal(out["actual_seq_len"].numpy(), g["collate.actual_seq_len"])
+    np.testing.assert_array_equal(out["image_indices"].numpy(), g["collate.image_indices"])
+    np.testing.assert_array_equal(out["images"].numpy(), g["collate.images"])
+    assert out["tokens"].shape == (3, 32)
+
+
+def test_frame_token_span_layout():
+    from long_vita_amd.packing import frame_token_span
+    ii, n = frame_token_span(3, 4)
+    pos, n2 = I.image_token_layout(3, 1, 4)
+    assert n == n2 == 9 and ii[1].tolist() == pos.tolist() and ii[0].sum() == 0
+    # 4096 frames of 258 tokens exceed 2**20: the "1M" context holds fewer frames
+    assert 4096 * 258 == 1056768 > 2 ** 20
+
+
+def test_flash_attention_forward_branch_errors():
+    from long_vita_amd import state
+    from long_vita_amd.core_attention import flash_attention_forward
+    state.set_args(state.make_args())
+    q = torch.zeros(8, 1, 2, 128, dtype=torch.bfloat16)
+    with pytest.raises(AssertionError, match="packed_seq_params should be None."):
+        flash_attention_forward(None, q, q, q, None, None, object())
+    import types
+    self = types.SimpleNamespace(hidden_size_per_attention_head=128, scale_mask_softmax=types.SimpleNamespace(scale=None),
+                                 softmax_scale=None, attention_dropout=types.SimpleNamespace(p=0.0), alibi=None)
+    state.set_args(state.make_args(reset_attention_mask=True))
+    state.set_actual_seq_len(None)
+    with pytest.raises(AssertionError):
+        flash_attention_forward(self, q, q, q, None, None, None)
+    state.set_actual_seq_len([8])
+    state.set_args(state.make_args(reset_attention_mask=True, context_parallel_size=2))
+    with pytest.raises(NotImplementedError):
+        flash_attention_forward(self, q, q, q, None, None, None)

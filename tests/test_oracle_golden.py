@@ -122,5 +122,20 @@ def test_pack_samples_semantics():
     assert img.shape == (2, 2, 4) and img[1].tolist() == pos0.tolist()
     actual, pids, img = I.pack_samples([10, 15], [None, pos0], 20)
     assert actual.tolist() == [10, 20] and len(pids) == 20
-    assert img[1].tolist() == (pos0 + 10).tolist()
+    assert img[1].tolist() == pos0.tolist()      # first image-bearing sample is NOT shifted (reference quirk)
     assert I.cu_seqlens_from_actual(actual).tolist() == [0, 10, 20]
+
+
+def test_pack_samples_matches_reference_add_ret_process_ret(golden_dir):
+    g = _load(golden_dir, "packing.npz")
+    img_a = [[2, 3, 4, 5], [8, 9, 10, 11]]
+    img_b = [[1, 2, 3, 4]]
+    cases = {"pad": ([(15, img_a), (9, None), (6, img_b)], 40, False),
+             "trunc": ([(15, None), (9, img_b), (20, None)], 32, False),
+             "late_image": ([(10, None), (12, img_b), (8, img_a)], 32, False),
+             "shift": ([(15, img_a), (9, None)], 32, True)}
+    for name, (samples, max_len, shift) in cases.items():
+        actual, pids, img = I.pack_samples([L for L, _ in samples], [i for _, i in samples], max_len, shift_token=shift)
+        np.testing.assert_array_equal(actual, g[f"{name}.actual_seq_len"], err_msg=name)
+        np.testing.assert_array_equal(pids, g[f"{name}.position_ids"], err_msg=name)
+        np.testing.assert_array_equal(img, g[f"{name}.image_indices"], err_msg=name)
