@@ -11,6 +11,7 @@
 // per-lane multiply.  K/V tiles are fetched global -> registers early and written to
 // the other LDS buffer after the tile's math (one barrier per tile).
 #include "internal.h"
+#include <type_traits>
 
 
 template <int D>
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
     constexpr int TILEB = BN * ROWB;  // bytes per K or V tile
     constexpr int CPR = D / 8;        // 16-byte chunks per row
     constexpr int NLD = (BN * CPR) / 512;  // 16-byte loads per thread per tile (2 or 1)
+    constexpr float RESCALE_LOG2 = 8.0f;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [K buf0][K buf1][V buf0][V buf1]
@@ -72,26 +74,36 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
     // waves whose 32 rows all lie past q_rows (short last block) only help with staging
     const int my_nkt = (32 * w < q_rows) ? (wave_kmax + BN - 1) / BN : 0;
 
-    // ---- staging addresses (global -> regs -> LDS)
-    const __bf16* kbase = p.k + (int64_t)kvh * p.k_hs;
-    const __bf16* vbase = p.v + (int64_t)kvh * p.v_hs;
-    int st_row[NLD], st_lds[NLD], st_col[NLD];
+    // ---- staging (global -> regs -> LDS) through buffer loads: the descriptor base moves
+    // to the tile's first key row (scalar arithmetic), the per-lane offset is fixed, and rows
+    // past the end of the key range read as zero (hardware bounds check), so the loop does no
+    // per-lane address arithmetic for global memory.
+    const char* kbase = reinterpret_cast<const char*>(p.k + (int64_t)kvh * p.k_hs + (int64_t)k_row0 * p.k_rs);
+    const char* vbase = reinterpret_cast<const char*>(p.v + (int64_t)kvh * p.v_hs + (int64_t)k_row0 * p.v_rs);
+    const int64_t k_tile_bytes = (int64_t)BN * p.k_rs * 2, v_tile_bytes = (int64_t)BN * p.v_rs * 2;
+    int st_lds[NLD], st_koff[NLD], st_voff[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        int c = tid + 512 * i;
-        st_row[i] = c / CPR;
-        int ch = c % CPR;
-        st_col[i] = ch * 8;
-        st_lds[i] = lds_off<D>(st_row[i], ch);
+        int cidx = tid + 512 * i;
+        int row = cidx / CPR, ch = cidx % CPR;
+        st_lds[i] = lds_off<D>(row, ch);
+        st_koff[i] = (int)(row * p.k_rs * 2) + ch * 16;
+        st_voff[i] = (int)(row * p.v_rs * 2) + ch * 16;
     }
+    const int rows_avail = min(k_len, p.k_rows_total - k_row0);  // key rows that exist from k_row0 on
     u32x4 kreg[NLD], vreg[NLD];
     auto issue_loads = [&](int t) {
+        int rows = rows_avail - t * BN;
+        rows = rows < 0 ? 0 : (rows > BN ? BN : rows);
+        // num_records: whole rows of this tile (the last row only up to the end of the head's columns)
+        uint32_t krec = rows ? (uint32_t)((rows - 1) * p.k_rs * 2 + ROWB) : 0u;
+        uint32_t vrec = rows ? (uint32_t)((rows - 1) * p.v_rs * 2 + ROWB) : 0u;
+        auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase + t * k_tile_bytes), 0, krec, 0x00020000);
+        auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase + t * v_tile_bytes), 0, vrec, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            int row = k_row0 + t * BN + st_row[i];
-            if (row > p.k_rows_total - 1) row = p.k_rows_total - 1;
-            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)row * p.k_rs + st_col[i]);
-            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)row * p.v_rs + st_col[i]);
+            kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, st_koff[i], 0, 0));
+            vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, st_voff[i], 0, 0));
         }
     };
     auto write_lds = [&](int buf) {
@@ -131,10 +143,17 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
         issue_loads(0);
         write_lds(0);
     }
+    // Retire the Q loads here: otherwise the compiler waits for them inside the loop with
+    // vmcnt(7..0) in front of the first MFMAs of every tile, which also drains the K/V
+    // prefetch issued at the top of the iteration.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     __syncthreads();
 
-    for (int t = 0; t < nkt; ++t) {
-        const int cur = t & 1;
+    // One K/V tile of the sweep; CUR (the LDS buffer) is a compile-time constant so that every
+    // LDS address is a lane-constant register plus an immediate.
+    auto tile = [&](int t, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
         const bool more = (t + 1 < nkt);
         if (more) issue_loads(t + 1);
 
@@ -172,10 +191,21 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
             mx = pair32_max(mx);
+            // Deferred rescale: the running maximum is only raised (and O, l rescaled) when some
+            // row of the wave saw its maximum grow by more than 2^RESCALE_LOG2; otherwise P is
+            // computed against the old maximum and is bounded by 2^RESCALE_LOG2.
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = fast_exp2((m_run - m_new) * c);
-            const float mc = m_new * c;
-            m_run = m_new;
+            const bool grow = (m_new - m_run) * c > RESCALE_LOG2;
+            if (__any(grow)) {
+                const float alpha = fast_exp2((m_run - m_new) * c);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[mt][i] *= alpha;
+            }
+            const float mc = m_run * c;
             float rs = 0.f;
             bf16x8 pf[2][2];
 #pragma unroll
@@ -186,11 +216,7 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
                     rs += pv;
                     pf[st][i >> 3][i & 7] = (__bf16)pv;
                 }
-            l_run = l_run * alpha + rs;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[mt][i] *= alpha;
+            l_run += rs;
             // ---- O^T += V^T P^T
 #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -210,6 +236,10 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
         }
         if (more) write_lds(cur ^ 1);
         __syncthreads();
+    };
+    for (int t = 0; t < nkt; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nkt) tile(t + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: normalise, store O (row-per-lane, 8-byte pieces) and LSE

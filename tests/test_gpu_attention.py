@@ -128,3 +128,29 @@ def test_backward_matches_oracle(name, cu, Hq, Hkv, D, causal):
     assert rel_err(qc.grad, rdq) <= REL_TOL
     assert rel_err(kc.grad, rdk) <= REL_TOL
     assert rel_err(vc.grad, rdv) <= REL_TOL
+
+
+def test_forward_rescale_branch_is_exercised():
+    """The kernel defers the running-max update until a row's maximum grows by more than
+    2^8; spike two keys so that the update fires in the middle of the key sweep (and a
+    second time later), far from the first tile, and check every row against float64."""
+    from long_vita_amd import ops
+    T, Hq, Hkv, D = 2048, 4, 2, 128
+    g = torch.Generator().manual_seed(77)
+    u = torch.randn(D, generator=g)
+    u = u / u.norm() * (D ** 0.5)
+    q = torch.randn(T, Hq, D, generator=g) * 0.3 + 2.0 * u
+    k = torch.randn(T, Hkv, D, generator=g) * 0.3
+    v = torch.randn(T, Hkv, D, generator=g)
+    k[500] = 3.0 * u          # score ~ 6*128/sqrt(128) = 68 -> far beyond the 2^8 threshold
+    k[1500, 0] = 6.0 * u      # second jump, one KV head only
+    q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    scale = A.default_scale(D)
+    ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, True)
+    out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, True)
+    assert rel_err(out, ref_o) <= REL_TOL
+    assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= 2e-3 * max(1.0, np.abs(ref_lse).max() / 10)
+    # non-causal: every row meets both spikes
+    ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, False)
+    out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, False)
+    assert rel_err(out, ref_o) <= REL_TOL
