@@ -46,6 +46,9 @@ extern "C" {
 
 /* Library identification / diagnostics. */
 int lvattn_abi_version(void);
+/* Query rows per forward work item (LV_FWD_BLOCK_M unless overridden by the environment
+ * variable LVATTN_FWD_WAVES=4, which selects 128-row items). */
+int lvattn_fwd_block_m(void);
 const char* lvattn_last_error(void);
 
 /* ---- host-side block builders (pure CPU, no HIP calls) -------------------

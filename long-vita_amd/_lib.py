@@ -24,6 +24,7 @@ _f = C.c_float
 _SIGNATURES = {
     "lvattn_abi_version": (C.c_int, []),
     "lvattn_last_error": (C.c_char_p, []),
+    "lvattn_fwd_block_m": (C.c_int, []),
     "lv_build_fwd_blocks": (_int, [_i32p, _int, _int, _i32p, _int]),
     "lv_build_bwd_blocks": (_int, [_i32p, _int, _int, _i32p, _int]),
     "lv_build_fwd_blocks_rect": (_int, [_int, _int, _int, _int, _int, _int, _i32p, _int]),

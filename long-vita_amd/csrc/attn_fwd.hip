@@ -20,21 +20,24 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     else return lds_off64(row, chunk);
 }
 
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
+template <int D, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
     constexpr int BN = 64;            // keys per tile
     constexpr int KS = D / 16;        // k-steps of the QK^T product
     constexpr int MT = D / 32;        // 32-wide d sub-tiles of the PV product
     constexpr int ROWB = D * 2;       // bytes per K/V row
     constexpr int TILEB = BN * ROWB;  // bytes per K or V tile
     constexpr int CPR = D / 8;        // 16-byte chunks per row
-    constexpr int NLD = (BN * CPR) / 512;  // 16-byte loads per thread per tile (2 or 1)
+    constexpr int NT = NW * 64;       // threads per workgroup
+    constexpr int NLD = (BN * CPR) / NT;  // 16-byte loads per thread per tile
     constexpr float RESCALE_LOG2 = 8.0f;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [K buf0][K buf1][V buf0][V buf1]
-    char* const ldsK = smem;
-    char* const ldsV = smem + 2 * TILEB;
+    // explicit LDS (address space 3) pointers: 32-bit address arithmetic, immediates fold
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const ldsK = (lds_char*)smem;
+    lds_char* const ldsV = ldsK + 2 * TILEB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
     int st_lds[NLD], st_koff[NLD], st_voff[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        int cidx = tid + 512 * i;
+        int cidx = tid + NT * i;
         int row = cidx / CPR, ch = cidx % CPR;
         st_lds[i] = lds_off<D>(row, ch);
         st_koff[i] = (int)(row * p.k_rs * 2) + ch * 16;
@@ -109,26 +112,26 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
     auto write_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            *reinterpret_cast<u32x4*>(ldsK + buf * TILEB + st_lds[i]) = kreg[i];
-            *reinterpret_cast<u32x4*>(ldsV + buf * TILEB + st_lds[i]) = vreg[i];
+            *(LDS_PTR(u32x4, ldsK + buf * TILEB + st_lds[i])) = kreg[i];
+            *(LDS_PTR(u32x4, ldsV + buf * TILEB + st_lds[i])) = vreg[i];
         }
     };
 
     // ---- LDS read addresses
     // K row read: row 32*st + r, chunk 2ks + h
-    int k_off[KS];
+    lds_char* k_ptr[KS];   // absolute LDS addresses (buffer 0, sub-tile 0); the rest are immediates
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) k_off[ks] = lds_off<D>(r, 2 * ks + h);
+    for (int ks = 0; ks < KS; ++ks) k_ptr[ks] = ldsK + lds_off<D>(r, 2 * ks + h);
     // V transposed read: 16-lane group g covers d columns 32mt + 16(g&1) + i, key rows
     // 16s + 8jh + 4h + q4 ; lane 4*q4 + p4 supplies row q4, columns 4*p4 .. 4*p4+3.
     const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gl = (lane >> 4) & 1;
-    int v_off[MT][2];
+    lds_char* v_ptr[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh) {
             int row = 8 * jh + 4 * h + q4;
-            v_off[mt][jh] = lds_off<D>(row, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
+            v_ptr[mt][jh] = ldsV + lds_off<D>(row, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
         }
 
     f32x16 oacc[MT];
@@ -158,8 +161,6 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
         if (more) issue_loads(t + 1);
 
         if (t < my_nkt) {
-            const char* kb = ldsK + cur * TILEB;
-            const char* vb = ldsV + cur * TILEB;
             // ---- S^T = K Q^T, two 32-key sub-tiles
             f32x16 s[2];
 #pragma unroll
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
                 for (int i = 0; i < 16; ++i) s[st][i] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + st * 32 * ROWB + k_off[ks]);
+                    bf16x8 kf = *(LDS_PTR(bf16x8, k_ptr[ks] + cur * TILEB + st * 32 * ROWB));
                     s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
                 }
             }
@@ -222,11 +223,11 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
             for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const char* vrow = vb + (32 * st + 16 * s2) * ROWB;
+                    const int voff = cur * TILEB + (32 * st + 16 * s2) * ROWB;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, vrow + v_off[mt][0]));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, vrow + v_off[mt][1]));
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][0] + voff));
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][1] + voff));
                         bf16x8 vf;
                         vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                         vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -264,17 +265,19 @@ __global__ __launch_bounds__(512) void lv_fwd_kernel(FwdParams p) {
     }
 }
 
-int lv_launch_fwd(const FwdParams& p, int d, int causal, hipStream_t stream) {
-    dim3 grid((unsigned)((int64_t)p.n_blocks * p.hq));
-    dim3 block(512);
+template <int D, int NW>
+static void launch_fwd_d(const FwdParams& p, int causal, hipStream_t stream) {
+    dim3 grid((unsigned)((int64_t)p.n_blocks * p.hq)), block(NW * 64);
+    size_t lds = 4 * 64 * D * 2;
+    if (causal) hipLaunchKernelGGL((lv_fwd_kernel<D, true, NW>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((lv_fwd_kernel<D, false, NW>), grid, block, lds, stream, p);
+}
+
+int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream) {
     if (d == 128) {
-        size_t lds = 4 * 64 * 256;
-        if (causal) hipLaunchKernelGGL((lv_fwd_kernel<128, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((lv_fwd_kernel<128, false>), grid, block, lds, stream, p);
+        if (waves == 4) launch_fwd_d<128, 4>(p, causal, stream); else launch_fwd_d<128, 8>(p, causal, stream);
     } else {
-        size_t lds = 4 * 64 * 128;
-        if (causal) hipLaunchKernelGGL((lv_fwd_kernel<64, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((lv_fwd_kernel<64, false>), grid, block, lds, stream, p);
+        if (waves == 4) launch_fwd_d<64, 4>(p, causal, stream); else launch_fwd_d<64, 8>(p, causal, stream);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -21,6 +22,17 @@ static int fail(int code, const char* fmt, ...) {
 }
 
 extern "C" int lvattn_abi_version(void) { return 1; }
+
+// Query rows per forward work item.  256 (8 waves per workgroup) by default; the
+// environment variable LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
+static int fwd_waves() {
+    static int w = [] {
+        const char* e = getenv("LVATTN_FWD_WAVES");
+        return (e && atoi(e) == 4) ? 4 : 8;
+    }();
+    return w;
+}
+extern "C" int lvattn_fwd_block_m(void) { return fwd_waves() * 32; }
 extern "C" const char* lvattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------
@@ -42,9 +54,10 @@ int emit(std::vector<HostDesc>& blocks, int32_t* out, int max_blocks) {
 
 // forward: query blocks of a rectangle q[q0, q0+ql) x k[k0, k0+kl)
 void fwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift) {
-    for (int m = 0; m < ql; m += LV_FWD_BLOCK_M) {
+    const int BM = lvattn_fwd_block_m();
+    for (int m = 0; m < ql; m += BM) {
         HostDesc d{};
-        int rows = std::min(LV_FWD_BLOCK_M, ql - m);
+        int rows = std::min(BM, ql - m);
         int klen = kl;
         int sh = 0;
         if (causal) {
@@ -146,7 +159,7 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
     p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
     p.o_rs = o_rs; p.o_hs = o_hs; p.lse_stride = lse_stride;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (lv_launch_fwd(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }
 

@@ -14,7 +14,7 @@ struct FwdParams {
     int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, o_rs, o_hs, lse_stride;
     float scale, scale_log2e;
 };
-int lv_launch_fwd(const FwdParams& p, int d, int causal, hipStream_t stream);
+int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 
 struct BwdParams {
     const __bf16* q;

@@ -55,7 +55,7 @@ def build_blocks_host(cu_seqlens: Sequence[int], causal: bool, backward: bool = 
     n_seg = cu.shape[0] - 1
     if n_seg < 0:
         raise LvAttnError("cu_seqlens must hold at least one entry")
-    blk = LV_BWD_BLOCK_N if backward else LV_FWD_BLOCK_M
+    blk = LV_BWD_BLOCK_N if backward else _lib.lib().lvattn_fwd_block_m()
     lens = np.diff(cu.astype(np.int64)) if n_seg else np.zeros(0, np.int64)
     max_blocks = int(np.sum((np.maximum(lens, 0) + blk - 1) // blk)) + 1
     out = np.zeros((max_blocks, LV_DESC_INTS), dtype=np.int32)
@@ -67,7 +67,7 @@ def build_blocks_host(cu_seqlens: Sequence[int], causal: bool, backward: bool = 
 def build_rect_blocks_host(q_row0: int, q_len: int, k_row0: int, k_len: int, causal: bool, shift: int = 0,
                            backward: bool = False) -> np.ndarray:
     """Descriptors for one rectangle of the score matrix (a ring step)."""
-    blk = LV_BWD_BLOCK_N if backward else LV_FWD_BLOCK_M
+    blk = LV_BWD_BLOCK_N if backward else _lib.lib().lvattn_fwd_block_m()
     span = k_len if backward else q_len
     max_blocks = (span + blk - 1) // blk + 1
     out = np.zeros((max_blocks, LV_DESC_INTS), dtype=np.int32)
