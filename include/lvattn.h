@@ -24,7 +24,8 @@
  *   [5..7] reserved, must be 0
  * The backward kernels use the transposed descriptor (one per key block):
  *   [0] k_row0  [1] k_rows (1 .. LV_BWD_BLOCK_N)  [2] q_row0  [3] q_len
- *   [4] shift   key k_row0+j visible to query q_row0+i iff j <= i + shift - ... (see lv_build_bwd_blocks)
+ *   [4] shift   key k_row0+j visible to query q_row0+i iff j <= i + shift (q_row0 is the first
+ *               32-aligned query row that sees any key of the block)
  */
 #ifndef LVATTN_H
 #define LVATTN_H
@@ -41,7 +42,7 @@ extern "C" {
 #define LV_ESIZE (-3)    /* output buffer too small */
 
 #define LV_FWD_BLOCK_M 256 /* query rows per forward work item  */
-#define LV_BWD_BLOCK_N 128 /* key rows per backward work item   */
+#define LV_BWD_BLOCK_N 128 /* key rows per dK/dV work item         */
 #define LV_DESC_INTS 8
 
 /* Library identification / diagnostics. */
@@ -94,11 +95,14 @@ int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* ls
  * Replaces the autograd of the calls above (npu_fusion_attention_grad, reached
  * through torch autograd from dot_product_attention.py:352-365 / :314-325) and the
  * per-step backward of the ring.
- * Step 1: delta[h, row] = sum_d dout*out (fp32 [hq, lse_stride]).
- * Step 2: per key block, accumulate dk/dv (bf16 out, or fp32 accumulate when
- *         dkv_accum_f32 != 0: dk/dv are then fp32 buffers that are ADDED to) and
- *         atomically add dq into the fp32 buffer dq_accum [rows, hq, d] (contiguous).
- * Step 3: lvattn_cast_f32_bf16 turns dq_accum into bf16 with the caller's strides. */
+ * Step 1: lvattn_bwd_delta: delta[h, row] = sum_d dout*out (fp32 [hq, lse_stride]).
+ * Step 2: lvattn_bwd launches two kernels, neither of which sums across workgroups
+ *         (no atomics; results are bitwise reproducible):
+ *           dK/dV: one work item per key block    (descriptors from lv_build_bwd_blocks*)
+ *           dQ   : one work item per query block  (descriptors from lv_build_fwd_blocks*)
+ *         With accum_f32 == 0, dq [rows,hq,d] / dk / dv [rows,hkv,d] are bf16 and written;
+ *         with accum_f32 != 0 they are fp32 buffers that are ADDED to (ring steps).
+ *         Strides of dq/dk/dv are in elements of their own type. */
 int lvattn_bwd_delta(const void* out, const void* dout, float* delta,
                      int rows, int hq, int d,
                      int64_t o_row_stride, int64_t o_head_stride,
@@ -106,17 +110,19 @@ int lvattn_bwd_delta(const void* out, const void* dout, float* delta,
                      int64_t lse_stride, void* stream);
 int lvattn_bwd(const void* q, const void* k, const void* v, const void* dout,
                const float* lse, const float* delta,
-               float* dq_accum, void* dk, void* dv,
-               const int32_t* desc_dev, int n_blocks,
+               void* dq, void* dk, void* dv,
+               const int32_t* qdesc_dev, int n_qblocks, const int32_t* kdesc_dev, int n_kblocks,
                int q_rows_total, int k_rows_total, int hq, int hkv, int d,
                int64_t q_row_stride, int64_t q_head_stride,
                int64_t k_row_stride, int64_t k_head_stride,
                int64_t v_row_stride, int64_t v_head_stride,
                int64_t do_row_stride, int64_t do_head_stride,
+               int64_t dq_row_stride, int64_t dq_head_stride,
                int64_t dk_row_stride, int64_t dk_head_stride,
                int64_t dv_row_stride, int64_t dv_head_stride,
-               int64_t lse_stride, float softmax_scale, int causal, int dkv_accum_f32,
+               int64_t lse_stride, float softmax_scale, int causal, int accum_f32,
                void* stream);
+/* fp32 [rows, heads, d] contiguous -> bf16 with strides (casting the ring's fp32 accumulators). */
 int lvattn_cast_f32_bf16(const float* src, void* dst, int rows, int heads, int d,
                          int64_t dst_row_stride, int64_t dst_head_stride, void* stream);
 

@@ -32,8 +32,8 @@ _SIGNATURES = {
     "lvattn_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                           _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _vp]),
     "lvattn_bwd_delta": (_int, [_vp, _vp, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp]),
-    "lvattn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
-                          _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+    "lvattn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _int, _int, _int, _int, _int,
+                          _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                           _f, _int, _int, _vp]),
     "lvattn_cast_f32_bf16": (_int, [_vp, _vp, _int, _int, _int, _i64, _i64, _vp]),
     "lvattn_merge": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _i64, _vp]),

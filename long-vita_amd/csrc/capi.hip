@@ -180,29 +180,34 @@ extern "C" int lvattn_bwd_delta(const void* out, const void* dout, float* delta,
 }
 
 extern "C" int lvattn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
-                          float* dq_accum, void* dk, void* dv, const int32_t* desc_dev, int n_blocks,
+                          void* dq, void* dk, void* dv,
+                          const int32_t* qdesc_dev, int n_qblocks, const int32_t* kdesc_dev, int n_kblocks,
                           int q_rows_total, int k_rows_total, int hq, int hkv, int d,
                           int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
-                          int64_t do_rs, int64_t do_hs, int64_t dk_rs, int64_t dk_hs, int64_t dv_rs, int64_t dv_hs,
-                          int64_t lse_stride, float scale, int causal, int dkv_accum_f32, void* stream) {
+                          int64_t do_rs, int64_t do_hs, int64_t dq_rs, int64_t dq_hs,
+                          int64_t dk_rs, int64_t dk_hs, int64_t dv_rs, int64_t dv_hs,
+                          int64_t lse_stride, float scale, int causal, int accum_f32, void* stream) {
     if (int e = check_common(q, k, v, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
-    if (!dout || !lse || !delta || !dq_accum || !dk || !dv || !desc_dev) return fail(LV_EINVAL, "null pointer");
+    if (!dout || !lse || !delta || !dq || !dk || !dv) return fail(LV_EINVAL, "null pointer");
+    if ((n_qblocks > 0 && !qdesc_dev) || (n_kblocks > 0 && !kdesc_dev)) return fail(LV_EINVAL, "null descriptor pointer");
     if (((uintptr_t)dout & 15) || ((do_rs | do_hs) & 7)) return fail(LV_EINVAL, "dout must be 16-byte aligned, strides % 8 == 0");
-    if ((((uintptr_t)dk | (uintptr_t)dv) & 15) || ((dk_rs | dk_hs | dv_rs | dv_hs) & 3))
-        return fail(LV_EINVAL, "dk/dv must be 16-byte aligned with strides % 4 == 0");
-    if ((uintptr_t)dq_accum & 15) return fail(LV_EINVAL, "dq_accum must be 16-byte aligned");
-    if (n_blocks < 0 || q_rows_total <= 0 || k_rows_total <= 0 || lse_stride < q_rows_total) return fail(LV_EINVAL, "bad sizes");
-    if (n_blocks == 0) return LV_OK;
+    if ((((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) || ((dq_rs | dq_hs | dk_rs | dk_hs | dv_rs | dv_hs) & 3))
+        return fail(LV_EINVAL, "dq/dk/dv must be 16-byte aligned with strides % 4 == 0");
+    if (n_qblocks < 0 || n_kblocks < 0 || q_rows_total <= 0 || k_rows_total <= 0 || lse_stride < q_rows_total)
+        return fail(LV_EINVAL, "bad sizes");
+    if (n_qblocks == 0 && n_kblocks == 0) return LV_OK;
+    if ((int64_t)n_qblocks * hq > 0x7fffffffLL || (int64_t)n_kblocks * hkv > 0x7fffffffLL) return fail(LV_EINVAL, "grid too large");
     BwdParams p;
     p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.dout = (const __bf16*)dout;
-    p.lse = lse; p.delta = delta; p.dq = dq_accum; p.dk = dk; p.dv = dv;
-    p.desc = (const AttnDesc*)desc_dev;
-    p.n_blocks = n_blocks; p.hq = hq; p.hkv = hkv; p.group = hq / hkv;
+    p.lse = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.desc = (const AttnDesc*)kdesc_dev; p.qdesc = (const AttnDesc*)qdesc_dev;
+    p.n_blocks = n_kblocks; p.n_qblocks = n_qblocks; p.hq = hq; p.hkv = hkv; p.group = hq / hkv;
     p.q_rows_total = q_rows_total; p.k_rows_total = k_rows_total;
     p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
-    p.do_rs = do_rs; p.do_hs = do_hs; p.dk_rs = dk_rs; p.dk_hs = dk_hs; p.dv_rs = dv_rs; p.dv_hs = dv_hs;
+    p.do_rs = do_rs; p.do_hs = do_hs; p.dq_rs = dq_rs; p.dq_hs = dq_hs;
+    p.dk_rs = dk_rs; p.dk_hs = dk_hs; p.dv_rs = dv_rs; p.dv_hs = dv_hs;
     p.lse_stride = lse_stride; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (lv_launch_bwd(p, d, causal, dkv_accum_f32, (hipStream_t)stream))
+    if (lv_launch_bwd(p, d, causal, accum_f32, (hipStream_t)stream))
         return fail(LV_ELAUNCH, "backward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }

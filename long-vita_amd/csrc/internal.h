@@ -16,6 +16,8 @@ struct FwdParams {
 };
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 
+#define LV_BWD_BLOCK_N_INTERNAL 128
+
 struct BwdParams {
     const __bf16* q;
     const __bf16* k;
@@ -23,13 +25,14 @@ struct BwdParams {
     const __bf16* dout;
     const float* lse;
     const float* delta;
-    float* dq;   // fp32 [rows, hq, d] contiguous, atomically accumulated
-    void* dk;    // bf16 (stored) or fp32 (accumulated)
+    void* dq;    // bf16 (stored) or fp32 (accumulated), as dk / dv
+    void* dk;
     void* dv;
-    const AttnDesc* desc;
-    int n_blocks, hq, hkv, group;
+    const AttnDesc* desc;    // key blocks (dK/dV kernel)
+    const AttnDesc* qdesc;   // query blocks (dQ kernel)
+    int n_blocks, n_qblocks, hq, hkv, group;
     int q_rows_total, k_rows_total;
-    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs, dk_rs, dk_hs, dv_rs, dv_hs, lse_stride;
+    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs, dq_rs, dq_hs, dk_rs, dk_hs, dv_rs, dv_hs, lse_stride;
     float scale, scale_log2e;
 };
 int lv_launch_bwd(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);

@@ -142,11 +142,12 @@ def attn_fwd_launch(q, k, v, desc: torch.Tensor, scale: float, causal: bool, out
     return out, lse
 
 
-def attn_bwd_launch(q, k, v, out, dout, lse, desc_bwd: torch.Tensor, scale: float, causal: bool,
-                    dq_accum=None, dk=None, dv=None, delta=None, dkv_accum_f32: bool = False):
-    """Backward of ``attn_fwd_launch``.  Returns (dq_accum fp32 [Rq,Hq,D], dk, dv).
-    ``dk``/``dv`` are bf16 [Rk,Hkv,D] (written) or, with ``dkv_accum_f32``, fp32
-    buffers that are added to.  ``dq_accum`` is added to (zero it first)."""
+def attn_bwd_launch(q, k, v, out, dout, lse, desc_q: torch.Tensor, desc_k: torch.Tensor, scale: float, causal: bool,
+                    dq=None, dk=None, dv=None, delta=None, accum_f32: bool = False):
+    """Backward of ``attn_fwd_launch``.  ``desc_q`` are the forward's query-block descriptors
+    (dQ kernel), ``desc_k`` the key-block descriptors (dK/dV kernel).  Returns (dq, dk, dv, delta):
+    bf16 tensors that are written or, with ``accum_f32``, fp32 buffers that are added to.
+    Rows no descriptor covers are left untouched (buffers allocated here start at zero)."""
     q, k, v, dout, out = (_last_contig(t) for t in (q, k, v, dout, out))
     _check_qkv(q, k, v)
     rq, hq, d = q.shape
@@ -156,19 +157,19 @@ def attn_bwd_launch(q, k, v, out, dout, lse, desc_bwd: torch.Tensor, scale: floa
         delta = torch.empty((hq, lse.stride(0)), dtype=torch.float32, device=q.device)
         check(L.lvattn_bwd_delta(_ptr(out), _ptr(dout), _ptr(delta), rq, hq, d, out.stride(0), out.stride(1),
                                  dout.stride(0), dout.stride(1), delta.stride(0), _stream()), "lvattn_bwd_delta")
-    if dq_accum is None:
-        dq_accum = torch.zeros((rq, hq, d), dtype=torch.float32, device=q.device)
+    dt = torch.float32 if accum_f32 else torch.bfloat16
+    if dq is None:
+        dq = torch.zeros((rq, hq, d), dtype=dt, device=q.device)
     if dk is None:
-        dt = torch.float32 if dkv_accum_f32 else torch.bfloat16
         dk = torch.zeros((rk, hkv, d), dtype=dt, device=q.device)
         dv = torch.zeros((rk, hkv, d), dtype=dt, device=q.device)
     check(L.lvattn_bwd(
-        _ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dq_accum), _ptr(dk), _ptr(dv),
-        _ptr(desc_bwd), desc_bwd.shape[0], rq, rk, hq, hkv, d,
+        _ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv),
+        _ptr(desc_q), desc_q.shape[0], _ptr(desc_k), desc_k.shape[0], rq, rk, hq, hkv, d,
         q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-        dout.stride(0), dout.stride(1), dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1),
-        lse.stride(0), float(scale), int(causal), int(dkv_accum_f32), _stream()), "lvattn_bwd")
-    return dq_accum, dk, dv, delta
+        dout.stride(0), dout.stride(1), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1),
+        lse.stride(0), float(scale), int(causal), int(accum_f32), _stream()), "lvattn_bwd")
+    return dq, dk, dv, delta
 
 
 def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor | None = None) -> torch.Tensor:
@@ -210,9 +211,9 @@ class _VarlenAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dlse):
         q, k, v, out, lse = ctx.saved_tensors
-        desc = blocks_on_device(ctx.cu_seqlens, ctx.causal, True, q.device)
-        dq_acc, dk, dv, _ = attn_bwd_launch(q, k, v, out, dout, lse, desc, ctx.scale, ctx.causal)
-        dq = cast_f32_to_bf16(dq_acc)
+        desc_q = blocks_on_device(ctx.cu_seqlens, ctx.causal, False, q.device)
+        desc_k = blocks_on_device(ctx.cu_seqlens, ctx.causal, True, q.device)
+        dq, dk, dv, _ = attn_bwd_launch(q, k, v, out, dout, lse, desc_q, desc_k, ctx.scale, ctx.causal)
         return dq, dk, dv, None, None, None
 
 

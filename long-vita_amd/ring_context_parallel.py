@@ -57,8 +57,9 @@ class HipBackend:
         return delta
 
     def block_bwd(self, q3, k3, v3, out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dk_acc, dv_acc):
-        desc = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, True, q3.device)
-        self.ops.attn_bwd_launch(q3, k3, v3, out3, dout3, lse, desc, scale, causal, dq_acc, dk_acc, dv_acc, delta, True)
+        desc_q = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, False, q3.device)
+        desc_k = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, True, q3.device)
+        self.ops.attn_bwd_launch(q3, k3, v3, out3, dout3, lse, desc_q, desc_k, scale, causal, dq_acc, dk_acc, dv_acc, delta, True)
 
     def cast(self, x_f32, dtype):
         if dtype == torch.bfloat16 and x_f32.dim() == 3:
