@@ -1,24 +1,31 @@
 #!/bin/bash
-# rocprofv3 passes for the forward kernel at S=131072 (run on the GPU box from the repo root).
-# usage: bash tools_prof.sh <tag>
-set -e
-TAG=${1:-x}
+# rocprofv3 passes over the default bench (1M-token prefill on one GPU); run on the GPU box from
+# the repo root:  bash tools_prof.sh <tag> [extra bench args]
+# Pass 1: kernel trace + stats.  Passes 2-4: PMC counters, each in a run of its own.
+TAG=${1:-x}; shift
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_$TAG
+OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$R/bench.py --seq 131072 --steps 1 --warmup 0 --no-cpu-baseline"
-timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/p1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- python3 $ARGS > $OUT/p1.log 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/p2 --pmc FETCH_SIZE -- python3 $ARGS > $OUT/p2.log 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/p3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 $ARGS > $OUT/p3.log 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/p4 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -- python3 $ARGS > $OUT/p4.log 2>&1
+ARGS="$R/bench.py --steps 1 --warmup 1 --no-cpu-baseline $@"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/p1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- python3 $ARGS > $OUT/p1.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/p2 --pmc FETCH_SIZE -- python3 $ARGS > $OUT/p2.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/p3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 $ARGS > $OUT/p3.log 2>&1 || exit 1
 cd $OUT && python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, json
+out = {}
 for f in sorted(glob.glob("p*/**/*counter_collection.csv", recursive=True)):
-    agg = collections.defaultdict(float)
+    agg = collections.defaultdict(float); n = collections.defaultdict(int)
     for row in csv.DictReader(open(f)):
-        if "lv_fwd_kernel" in row["Kernel_Name"]:
-            agg[row["Counter_Name"]] += float(row["Counter_Value"])
-    print(f, dict(agg))
+        if "lv_" in row["Kernel_Name"]:
+            key = row["Kernel_Name"].split("(")[0] + "|" + row["Counter_Name"]
+            agg[key] += float(row["Counter_Value"]); n[key] += 1
+    for k in agg:
+        out[k] = {"sum": agg[k], "dispatches": n[k], "per_dispatch": agg[k] / n[k]}
+json.dump(out, open("pmc_summary.json", "w"), indent=1)
+for k, v in out.items():
+    print(k, v)
 PY
+cat $OUT/trace/*/*kernel_stats.csv | cut -c1-200 | head -4
