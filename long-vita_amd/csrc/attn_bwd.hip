@@ -4,7 +4,7 @@
 //
 // lv_bwd_dkdv_kernel  : one workgroup = 4 waves = one 128-key block of one K/V head; wave w
 //   keeps the K, V fragments and the dK^T, dV^T accumulators of its 32 keys in registers (key on the lane) while the workgroup
-//   sweeps the query heads of the group x 32-row query slices staged in LDS:
+//   sweeps 32-row query slices (last to first) x the query heads of the group, staged in LDS:
 //     S  = Q K^T        (A = Q rows from LDS,  B = K fragments in registers)
 //     P  = exp2(S*c - lse*log2e)
 //     dV^T += dO^T P    (A = dO read column-wise with ds_read_b64_tr_b16, B = P registers)
@@ -27,10 +27,28 @@
 
 typedef __attribute__((address_space(3))) char lds_char;
 
+#ifndef LV_BWD_RING
+#define LV_BWD_RING 4   // LDS slots of the dK/dV kernel's Q / dO staging ring
+#endif
 #ifndef LV_BWD_KT
 #define LV_BWD_KT 1   // key sub-tiles per wave of the dK/dV kernel; LV_BWD_BLOCK_N = 128 * LV_BWD_KT
 #endif
 static_assert(128 * LV_BWD_KT == LV_BWD_BLOCK_N_INTERNAL, "keep in step with LV_BWD_BLOCK_N in lvattn.h");
+
+// Direct global -> LDS loads (no register destination): lane i's 16 (or 4) bytes land at LDS byte
+// address lds_dst + 16 i (or 4 i); lds_dst is wave-uniform and travels in M0.  Written as asm so that
+// the compiler does not count them: it would otherwise wait for ALL of them before the next
+// transposed LDS read.  Their completion is waited for by hand (counted s_waitcnt vmcnt + barrier).
+__device__ __forceinline__ void dma16_buffer(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4_global(const float* g, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
 
 template <int D>
 __device__ __forceinline__ int lds_offd(int row, int chunk) {
@@ -75,22 +93,28 @@ int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows,
 template <int D, bool CAUSAL, bool ACCUM_F32>
 __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     constexpr int NW = 4;              // one wave per SIMD: the whole 512-register file per wave
-    constexpr int NT = NW * 64;
-    constexpr int KT = LV_BWD_KT;      // 32-key sub-tiles per wave (32*KT keys per wave, 128*KT per workgroup)
+    constexpr int KT = LV_BWD_KT;      // 32-key sub-tiles per wave (32 keys per wave, 128 per workgroup)
+    static_assert(KT == 1, "the software-pipelined loop below handles one key sub-tile per wave");
     constexpr int BQ = 32;             // query rows per slice
     constexpr int KS = D / 16;         // k-steps over d
     constexpr int MT = D / 32;         // 32-wide d sub-tiles
     constexpr int ROWB = D * 2;        // bytes per Q/dO row in LDS
     constexpr int CPR = D / 8;         // 16-byte chunks per row
     constexpr int QTILE = BQ * ROWB;   // bytes of a Q (or dO) slice
-    constexpr int NLD = (2 * BQ * CPR) / NT;  // 16-byte loads per thread per slice (Q and dO together)
+    // LDS ring of NBUF slots.  While slice `it` is computed on, slice it+1 is read for S, and the
+    // slices up to it+NBUF-1 are in flight from memory.  One slot:
+    //   [Q slice][dO slice][4 x (32 lse, 32 delta) f32: one copy per wave]
+    constexpr int NBUF = LV_BWD_RING;
+    constexpr int AHEAD = NBUF - 1;            // staging distance in slices
+    constexpr int SLOTB = 2 * QTILE + NW * 256;
+    // Staging is done by direct global->LDS loads; each wave-instruction writes 1 KiB of LDS
+    // (lane i -> bytes 16i..16i+15), i.e. RPP whole rows of the image.
+    constexpr int RPP = 64 / CPR;                  // rows per 1-KiB piece: 4 (d=128) or 8 (d=64)
+    constexpr int PPW = (2 * QTILE / 1024) / NW;   // pieces per wave per slice: 4 or 2
+    constexpr int LPI = PPW + 1;                   // loads per wave per slice (pieces + the lse/delta row)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [Q buf0][dO buf0][Q buf1][dO buf1][lse2 2x32 f32][delta 2x32 f32]
     lds_char* const lds0 = (lds_char*)smem;
-    constexpr int SLICEB = 2 * QTILE;  // Q + dO of one slice
-    float* const ldsL = reinterpret_cast<float*>(smem + 2 * SLICEB);
-    float* const ldsD = ldsL + 2 * BQ;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,66 +133,78 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     const int nslice = (q_len + BQ - 1) / BQ;
     const int niter = nslice * p.group;
 
-    // ---- K / V fragments -> registers (B operands; this lane's keys = 64w + 32kt + r)
-    const int kbase_w = 32 * KT * w;
-    bf16x8 kf[KT][KS], vf[KT][KS];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        int kj = kbase_w + 32 * kt + r;
+    // ---- K / V fragments -> registers (B operands; this lane's key = 32w + r)
+    const int kbase_w = 32 * w;
+    const int kj = kbase_w + r;
+    bf16x8 kf[KS], vf[KS];
+    {
         int grow = k_row0 + (kj < k_rows ? kj : k_rows - 1);
         const __bf16* kp = p.k + (int64_t)grow * p.k_rs + (int64_t)kvh * p.k_hs + 8 * h;
         const __bf16* vp = p.v + (int64_t)grow * p.v_rs + (int64_t)kvh * p.v_hs + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[kt][ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
-            vf[kt][ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
         }
     }
-
-    // ---- staging of a (head, slice): Q and dO rows, and the per-row lse*log2e / delta
-    int sg_lds[NLD], sg_row[NLD], sg_col[NLD];
-    bool sg_is_do[NLD];
+    // retire these loads now: inside the loop the only memory counter traffic is the staging
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        int cidx = tid + NT * i;
-        sg_is_do[i] = cidx >= BQ * CPR;
-        int cc = sg_is_do[i] ? cidx - BQ * CPR : cidx;
-        sg_row[i] = cc / CPR;
-        int ch = cc % CPR;
-        sg_col[i] = ch * 8;
-        sg_lds[i] = (sg_is_do[i] ? QTILE : 0) + lds_offd<D>(sg_row[i], ch);
+    for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(kf[ks])); asm volatile("" : "+v"(vf[ks])); }
+
+    // ---- staging of a (slice, head).  Waves 0,1 bring the Q rows, waves 2,3 the dO rows; piece j
+    // of wave w is rows RPP*(PPW*(w&1) + j) .. +RPP-1.  The LDS image is XOR-swizzled inside each
+    // row, and as the LDS side of the transfer is lane-linear the swizzle goes on the source:
+    // lane i of a piece holds position (i % CPR) of row (i / CPR), which must receive the global
+    // chunk (i % CPR) ^ f(row).
+    const bool w_is_do = (w >= NW / 2);
+    const int64_t x_rs = w_is_do ? p.do_rs : p.q_rs;
+    const int64_t x_hs = w_is_do ? p.do_hs : p.q_hs;
+    const __bf16* const x_base = (w_is_do ? p.dout : p.q) + (int64_t)q_row0 * x_rs;
+    const int prow0 = RPP * PPW * (w & 1) + lane / CPR;  // row of this lane in piece 0
+    int pch16[PPW], voff_full[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = prow0 + RPP * j;
+        // position -> chunk is the same involution as chunk -> position
+        pch16[j] = (lds_offd<D>(row, lane % CPR) - row * ROWB);
+        voff_full[j] = row * (int)(x_rs * 2) + pch16[j];
     }
-    u32x4 sreg[NLD];
-    float lreg = 0.f, dreg = 0.f;
-    auto issue_loads = [&](int it) {
-        int hg = it / nslice, sl = it - hg * nslice;
-        int head = kvh * p.group + hg;
+    const float* const ld_base = ((lane < 32) ? p.lse : p.delta) + q_row0;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds0);
+    // Iteration order: query slices from the LAST one down to the first, and for each slice the
+    // query heads of the group.  Key blocks of one sequence all end at the same query row, so
+    // workgroups that start together read the same Q / dO rows at the same time (L2 reuse).
+    int ld_sl = nslice - 1, ld_hg = 0;  // (slice, head) of the next staging request
+    auto issue_dma = [&](auto slot_c) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int sl = ld_sl, hg = ld_hg;
+        if (++ld_hg == p.group) { ld_hg = 0; --ld_sl; }
+        const int head = kvh * p.group + hg;
+        const int rows_valid = min(BQ, q_len - sl * BQ);  // >= 1; rows past it repeat the last valid row
+        const __bf16* base = x_base + (int64_t)head * x_hs + (int64_t)sl * BQ * x_rs;
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(base), 0, (uint32_t)((rows_valid - 1) * x_rs * 2 + ROWB), 0x00020000);
+        const uint32_t dst = lds_base + slot * SLOTB + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            int ql = sl * BQ + sg_row[i];
-            int grow = q_row0 + (ql < q_len ? ql : q_len - 1);
-            const __bf16* src = sg_is_do[i] ? p.dout + (int64_t)grow * p.do_rs + (int64_t)head * p.do_hs
-                                            : p.q + (int64_t)grow * p.q_rs + (int64_t)head * p.q_hs;
-            sreg[i] = *reinterpret_cast<const u32x4*>(src + sg_col[i]);
+        for (int j = 0; j < PPW; ++j) {
+            int voff = voff_full[j];
+            if (rows_valid < BQ) voff = min(prow0 + RPP * j, rows_valid - 1) * (int)(x_rs * 2) + pch16[j];
+            dma16_buffer(rs, voff, dst + j * 1024);
         }
-        if (tid < BQ) {
-            int ql = sl * BQ + tid;
-            int grow = q_row0 + (ql < q_len ? ql : q_len - 1);
-            float l = p.lse[(int64_t)head * p.lse_stride + grow];
-            lreg = (l == -INFINITY) ? INFINITY : l * 1.4426950408889634f;  // rows without keys: P = 0
-            dreg = p.delta[(int64_t)head * p.lse_stride + grow];
-        }
+        // lanes 0..31: lse of rows 0..31, lanes 32..63: delta of rows 0..31; every wave keeps its own copy
+        const float* gp = ld_base + (int64_t)head * p.lse_stride + sl * BQ + min(r, rows_valid - 1);
+        dma4_global(gp, lds_base + slot * SLOTB + 2 * QTILE + w * 256);
     };
-    auto write_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) *(LDS_PTR(u32x4, lds0 + buf * SLICEB + sg_lds[i])) = sreg[i];
-        if (tid < BQ) {
-            ldsL[buf * BQ + tid] = lreg;
-            ldsD[buf * BQ + tid] = dreg;
+    // issue into the slot of slice `it`, known at compile time only modulo NBUF
+    auto issue_dma_rt = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (NBUF == 4) {
+            if (slot == 0) issue_dma(std::integral_constant<int, 0>{});
+            else if (slot == 1) issue_dma(std::integral_constant<int, 1>{});
+            else if (slot == 2) issue_dma(std::integral_constant<int, 2>{});
+            else issue_dma(std::integral_constant<int, 3>{});
         }
     };
 
-    // ---- LDS read addresses (buffer 0; the other buffer and dO are immediates)
+    // ---- LDS read addresses (slot 0; the other slots and dO are immediates)
     lds_char* a_ptr[KS];  // row reads of Q: row r, chunk 2ks + h
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a_ptr[ks] = lds0 + lds_offd<D>(r, 2 * ks + h);
@@ -179,72 +215,97 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh)
             t_ptr[mt][jh] = lds0 + lds_offd<D>(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
+    // this wave's copy of the row constants: lse of rows 8g+4h .. +3 and delta of the same rows
+    lds_char* const ld_ptr = lds0 + 2 * QTILE + w * 256 + 16 * h;
 
-    f32x16 dk[KT][MT], dv[KT][MT];
+    f32x16 dk[MT], dv[MT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { dk[kt][mt][i] = 0.f; dv[kt][mt][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { dk[mt][i] = 0.f; dv[mt][i] = 0.f; }
     const float c = p.scale_log2e;
+    const float neg_inv_scale = -1.f / p.scale;
 
-    if (niter > 0) {
-        issue_loads(0);
-        write_lds(0);
-    }
-    // retire the K/V fragment loads before the loop (no vmcnt for them inside it)
+    // does any (query, key) pair of this wave survive the mask in the slice that starts at row i0?
+    auto wave_active = [&](int i0) { return (kbase_w <= i0 + BQ - 1 + shift) && (kbase_w < k_rows); };
+    // S' = Q K^T - lse / scale for the slice in LDS slot `buf`: the row constant goes in as the
+    // initial accumulator, so that P = exp2(c * S') needs no subtraction.
+    f32x16 sv;
+    auto compute_s = [&](auto buf_c) __attribute__((always_inline)) {
+        constexpr int SB = decltype(buf_c)::value * SLOTB;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+        for (int g = 0; g < 4; ++g) {
+            f32x4 l4 = *(LDS_PTR(f32x4, ld_ptr + SB + 32 * g));
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(kf[kt][ks])); asm volatile("" : "+v"(vf[kt][ks])); }
-    __syncthreads();
+            for (int e = 0; e < 4; ++e) sv[4 * g + e] = l4[e] * neg_inv_scale;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 qa = *(LDS_PTR(bf16x8, a_ptr[ks] + SB));
+            sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sv, 0, 0, 0);
+        }
+    };
+    // Wait until at most `n` of this wave's staging loads are in flight, then the workgroup barrier.
+    // (A plain __syncthreads() would wait for ALL of them: staging loads are pending LDS writes.)
+    auto wait_and_barrier = [&](bool leave_newest) __attribute__((always_inline)) {
+        if (leave_newest) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 2) * LPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
 
-    auto body = [&](int it, auto cur_c) {
+    // prologue: slices 0 .. AHEAD-1 requested, 0 and 1 landed
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < niter) issue_dma_rt(i);
+    wait_and_barrier(niter >= AHEAD);
+
+    // ---- the sweep, software-pipelined so that the matrix pipe has independent work while the
+    // vector pipe turns S into P and dP into dS (one wave per SIMD: nothing else would fill it):
+    //   dP'(it) = dO V^T - delta  | P(it) = exp2(c * S'(it))          S'(it) came from the previous iteration
+    //   dV     += dO^T P(it)      | dS(it) = P * dP' * scale
+    //   S'(it+1) = Q(it+1) K^T - lse / scale
+    //   dK     += Q^T dS(it)
+    int c_sl = nslice - 1, c_hg = 0;  // (slice, head) being computed
+    if (niter > 0 && wave_active(c_sl * BQ)) compute_s(std::integral_constant<int, 0>{});
+    auto body = [&](int it, auto cur_c) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_c)::value;
-        constexpr int QB = cur * SLICEB;          // Q of this buffer
-        constexpr int OB = cur * SLICEB + QTILE;  // dO of this buffer
-        const bool more = (it + 1 < niter);
-        const int sl = it % nslice;
-        const int i0 = sl * BQ;  // first query row of the slice, relative to q_row0
-        if (more) issue_loads(it + 1);
-
-        // does any (query, key) pair of this wave survive the mask?  keys 64w .. 64w+63
-        const bool active = (kbase_w <= i0 + BQ - 1 + shift) && (kbase_w < k_rows);
+        constexpr int nxt = (cur + 1) % NBUF, wr = (cur + AHEAD) % NBUF;
+        constexpr int QB = cur * SLOTB;          // Q of this slot
+        constexpr int OB = cur * SLOTB + QTILE;  // dO of this slot
+        const bool stage = (it + AHEAD < niter);
+        const int i0 = c_sl * BQ;  // first query row of the slice, relative to q_row0
+        if (++c_hg == p.group) { c_hg = 0; --c_sl; }
+        // slot `wr` held slice it-1, which every wave finished with before the last barrier
+        if (stage) issue_dma(std::integral_constant<int, wr>{});
+        const bool active = wave_active(i0);
+        const bool active_next = (it + 1 < niter) && wave_active(c_sl * BQ);
+        bf16x8 pf[2];
         if (active) {
-            const bool need_mask = (kbase_w + 32 * KT - 1 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 * KT > k_rows);
-            bf16x8 pf[KT][2];
-            {
-                // ---- S = Q K^T and P = exp2(S*c - lse2) (masked, kept as bf16), one key sub-tile
-                // at a time: the Q fragments are read twice, but only 16 accumulator registers
-                // are live beside the 384 that hold K, V, dK and dV.
-                f32x4 l4[4];
+            const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+            // dP' = dO V^T - delta (matrix pipe) beside P = exp2(c * S') (vector pipe)
+            f32x16 dp;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) l4[g] = *reinterpret_cast<const f32x4*>(ldsL + cur * BQ + 8 * g + 4 * h);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 d4 = *(LDS_PTR(f32x4, ld_ptr + QB + 32 * g + 128));
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    f32x16 sv;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sv[i] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        bf16x8 qa = *(LDS_PTR(bf16x8, a_ptr[ks] + QB));
-                        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kt][ks], sv, 0, 0, 0);
-                    }
-                    const int kj = kbase_w + 32 * kt + r;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float pv = fast_exp2(__builtin_fmaf(sv[i], c, -l4[i >> 2][i & 3]));
-                        if (need_mask) {
-                            int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            bool dead = (kj > ii + shift) || (ii >= q_len) || (kj >= k_rows);
-                            pv = dead ? 0.f : pv;
-                        }
-                        pf[kt][i >> 3][i & 7] = (__bf16)pv;
-                    }
-                }
+                for (int e = 0; e < 4; ++e) dp[4 * g + e] = -d4[e];
             }
-            // ---- dV^T += dO^T P  (each transposed A fragment is read once)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 oa = *(LDS_PTR(bf16x8, a_ptr[ks] + OB));
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float pv = fast_exp2(sv[i] * c);
+                if (need_mask) {
+                    int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    bool dead = (kj > ii + shift) || (ii >= q_len) || (kj >= k_rows);
+                    pv = dead ? 0.f : pv;
+                }
+                pf[i >> 3][i & 7] = (__bf16)pv;
+            }
+            // dV^T += dO^T P (matrix pipe) beside dS = P * dP' * scale (vector pipe)
+            bf16x8 dsf[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -254,32 +315,20 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
                     bf16x8 af;
                     af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
                     af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) dv[kt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[kt][s2], dv[kt][mt], 0, 0, 0);
+                    dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[s2], dv[mt], 0, 0, 0);
                 }
-            // ---- dP = dO V^T ; dS = P * (dP - delta) * scale, overwriting P; one sub-tile at a time
-            {
-                f32x4 d4[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) d4[g] = *reinterpret_cast<const f32x4*>(ldsD + cur * BQ + 8 * g + 4 * h);
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    f32x16 dp;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) dp[i] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        bf16x8 oa = *(LDS_PTR(bf16x8, a_ptr[ks] + OB));
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[kt][ks], dp, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float pv = (float)pf[kt][i >> 3][i & 7];
-                        pf[kt][i >> 3][i & 7] = (__bf16)(pv * (dp[i] - d4[i >> 2][i & 3]) * p.scale);
-                    }
-                }
+            for (int i = 0; i < 16; ++i) {
+                float pb = (float)pf[i >> 3][i & 7];  // the rounded P, as dV saw it
+                dsf[i >> 3][i & 7] = (__bf16)(pb * dp[i] * p.scale);
             }
-            // ---- dK^T += Q^T dS
+            pf[0] = dsf[0];
+            pf[1] = dsf[1];
+        }
+        // S' of the next slice: independent of everything above, keeps the matrix pipe busy while dS is formed
+        if (active_next) compute_s(std::integral_constant<int, nxt>{});
+        if (active) {
+            // dK^T += Q^T dS
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -289,48 +338,47 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
                     bf16x8 af;
                     af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
                     af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) dk[kt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[kt][s2], dk[kt][mt], 0, 0, 0);
+                    dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[s2], dk[mt], 0, 0, 0);
                 }
         }
-        if (more) write_lds(cur ^ 1);
-        __syncthreads();
+        // slice it+2 must have landed before the next iteration reads it for S'; the requests
+        // issued after it (it+3 .. it+AHEAD) stay in flight across the barrier
+        wait_and_barrier(stage);
     };
-    for (int it = 0; it < niter; it += 2) {
+    static_assert(NBUF == 4, "the loop below is unrolled over a ring of 4 slots");
+    for (int it = 0; it < niter; it += 4) {
         body(it, std::integral_constant<int, 0>{});
         if (it + 1 < niter) body(it + 1, std::integral_constant<int, 1>{});
+        if (it + 2 < niter) body(it + 2, std::integral_constant<int, 2>{});
+        if (it + 3 < niter) body(it + 3, std::integral_constant<int, 3>{});
     }
 
     // ---- epilogue: dK^T / dV^T accumulators (key on the lane) -> rows of dk / dv
+    if (kj < k_rows) {
+        const int64_t grow = k_row0 + kj;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int kj = kbase_w + 32 * kt + r;
-        if (kj < k_rows) {
-            const int64_t grow = k_row0 + kj;
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dcol = 32 * mt + 8 * g4 + 4 * h;
+                if constexpr (ACCUM_F32) {
+                    float* dkp = reinterpret_cast<float*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
+                    float* dvp = reinterpret_cast<float*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
+                    f32x4 a = *reinterpret_cast<f32x4*>(dkp), b = *reinterpret_cast<f32x4*>(dvp);
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int dcol = 32 * mt + 8 * g4 + 4 * h;
-                    if constexpr (ACCUM_F32) {
-                        float* dkp = reinterpret_cast<float*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
-                        float* dvp = reinterpret_cast<float*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
-                        f32x4 a = *reinterpret_cast<f32x4*>(dkp), b = *reinterpret_cast<f32x4*>(dvp);
+                    for (int e = 0; e < 4; ++e) { a[e] += dk[mt][4 * g4 + e]; b[e] += dv[mt][4 * g4 + e]; }
+                    *reinterpret_cast<f32x4*>(dkp) = a;
+                    *reinterpret_cast<f32x4*>(dvp) = b;
+                } else {
+                    __bf16* dkp = reinterpret_cast<__bf16*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
+                    __bf16* dvp = reinterpret_cast<__bf16*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
+                    bf16x4 a, b;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[e] += dk[kt][mt][4 * g4 + e]; b[e] += dv[kt][mt][4 * g4 + e]; }
-                        *reinterpret_cast<f32x4*>(dkp) = a;
-                        *reinterpret_cast<f32x4*>(dvp) = b;
-                    } else {
-                        __bf16* dkp = reinterpret_cast<__bf16*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
-                        __bf16* dvp = reinterpret_cast<__bf16*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
-                        bf16x4 a, b;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[e] = (__bf16)dk[kt][mt][4 * g4 + e]; b[e] = (__bf16)dv[kt][mt][4 * g4 + e]; }
-                        *reinterpret_cast<bf16x4*>(dkp) = a;
-                        *reinterpret_cast<bf16x4*>(dvp) = b;
-                    }
+                    for (int e = 0; e < 4; ++e) { a[e] = (__bf16)dk[mt][4 * g4 + e]; b[e] = (__bf16)dv[mt][4 * g4 + e]; }
+                    *reinterpret_cast<bf16x4*>(dkp) = a;
+                    *reinterpret_cast<bf16x4*>(dvp) = b;
                 }
-        }
+            }
     }
 }
 
@@ -547,7 +595,7 @@ static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stre
     if (p.n_blocks > 0) {
         dim3 grid((unsigned)((int64_t)p.n_blocks * p.hkv));
         dim3 block(256);
-        size_t lds = (size_t)4 * 32 * D * 2 + 4 * 32 * sizeof(float);
+        size_t lds = (size_t)LV_BWD_RING * (2 * 32 * D * 2 + 4 * 256);  // ring slots of (Q slice, dO slice, row constants)
         if (causal) {
             if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_kernel<D, true, true>), grid, block, lds, stream, p);
             else hipLaunchKernelGGL((lv_bwd_dkdv_kernel<D, true, false>), grid, block, lds, stream, p);
