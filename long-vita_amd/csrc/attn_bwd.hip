@@ -175,15 +175,17 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     // query heads of the group.  Key blocks of one sequence all end at the same query row, so
     // workgroups that start together read the same Q / dO rows at the same time (L2 reuse).
     int ld_sl = nslice - 1, ld_hg = 0;  // (slice, head) of the next staging request
-    auto issue_dma = [&](auto slot_c) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slot_c)::value;
+    int ld_slot = 0;                    // ring slot it goes to
+    auto issue_dma = [&]() __attribute__((always_inline)) {
         const int sl = ld_sl, hg = ld_hg;
         if (++ld_hg == p.group) { ld_hg = 0; --ld_sl; }
+        const uint32_t slot_base = lds_base + ld_slot * SLOTB;
+        if (++ld_slot == NBUF) ld_slot = 0;
         const int head = kvh * p.group + hg;
         const int rows_valid = min(BQ, q_len - sl * BQ);  // >= 1; rows past it repeat the last valid row
         const __bf16* base = x_base + (int64_t)head * x_hs + (int64_t)sl * BQ * x_rs;
         auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(base), 0, (uint32_t)((rows_valid - 1) * x_rs * 2 + ROWB), 0x00020000);
-        const uint32_t dst = lds_base + slot * SLOTB + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
+        const uint32_t dst = slot_base + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             int voff = voff_full[j];
@@ -192,19 +194,10 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
         }
         // lanes 0..31: lse of rows 0..31, lanes 32..63: delta of rows 0..31; every wave keeps its own copy
         const float* gp = ld_base + (int64_t)head * p.lse_stride + sl * BQ + min(r, rows_valid - 1);
-        dma4_global(gp, lds_base + slot * SLOTB + 2 * QTILE + w * 256);
-    };
-    // issue into the slot of slice `it`, known at compile time only modulo NBUF
-    auto issue_dma_rt = [&](int slot) __attribute__((always_inline)) {
-        if constexpr (NBUF == 4) {
-            if (slot == 0) issue_dma(std::integral_constant<int, 0>{});
-            else if (slot == 1) issue_dma(std::integral_constant<int, 1>{});
-            else if (slot == 2) issue_dma(std::integral_constant<int, 2>{});
-            else issue_dma(std::integral_constant<int, 3>{});
-        }
+        dma4_global(gp, slot_base + 2 * QTILE + w * 256);
     };
 
-    // ---- LDS read addresses (slot 0; the other slots and dO are immediates)
+    // ---- LDS read addresses in slot 0 (the slot offset is added per iteration, dO is an immediate)
     lds_char* a_ptr[KS];  // row reads of Q: row r, chunk 2ks + h
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a_ptr[ks] = lds0 + lds_offd<D>(r, 2 * ks + h);
@@ -217,6 +210,9 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
             t_ptr[mt][jh] = lds0 + lds_offd<D>(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
     // this wave's copy of the row constants: lse of rows 8g+4h .. +3 and delta of the same rows
     lds_char* const ld_ptr = lds0 + 2 * QTILE + w * 256 + 16 * h;
+    // and the same copy seen one float per lane (lanes 0..31 lse, 32..63 delta), for the rescaling pass
+    lds_char* const ld_lane_ptr = lds0 + 2 * QTILE + w * 256 + 4 * lane;
+    const float ld_lane_mul = (lane < 32) ? 1.4426950408889634f : 1.f;
 
     f32x16 dk[MT], dv[MT];
 #pragma unroll
@@ -224,29 +220,37 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[mt][i] = 0.f; dv[mt][i] = 0.f; }
     const float c = p.scale_log2e;
-    const float neg_inv_scale = -1.f / p.scale;
 
-    // does any (query, key) pair of this wave survive the mask in the slice that starts at row i0?
-    auto wave_active = [&](int i0) { return (kbase_w <= i0 + BQ - 1 + shift) && (kbase_w < k_rows); };
-    // S' = Q K^T - lse / scale for the slice in LDS slot `buf`: the row constant goes in as the
-    // initial accumulator, so that P = exp2(c * S') needs no subtraction.
-    f32x16 sv;
-    auto compute_s = [&](auto buf_c) __attribute__((always_inline)) {
-        constexpr int SB = decltype(buf_c)::value * SLOTB;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 l4 = *(LDS_PTR(f32x4, ld_ptr + SB + 32 * g));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sv[4 * g + e] = l4[e] * neg_inv_scale;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 qa = *(LDS_PTR(bf16x8, a_ptr[ks] + SB));
-            sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sv, 0, 0, 0);
-        }
+    // The staged lse is in natural-log units; the wave rewrites ITS copy as lse * log2(e) (one float
+    // per lane) before the first use, instead of 16 multiplications per lane in the product loop.
+    auto rescale_lse = [&](int sb) __attribute__((always_inline)) {
+        float v = *(LDS_PTR(float, ld_lane_ptr + sb));
+        *(LDS_PTR(float, ld_lane_ptr + sb)) = v * ld_lane_mul;
     };
-    // Wait until at most `n` of this wave's staging loads are in flight, then the workgroup barrier.
-    // (A plain __syncthreads() would wait for ALL of them: staging loads are pending LDS writes.)
+    // LDS -> register fragment loads for the slot at byte offset sb
+    auto load_rows = [&](bf16x8 (&f)[KS], int sb) __attribute__((always_inline)) {  // A operand: 32 rows x d
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f[ks] = *(LDS_PTR(bf16x8, a_ptr[ks] + sb));
+    };
+    auto load_cols = [&](bf16x8 (&f)[2 * MT], int sb) __attribute__((always_inline)) {  // A operand: d x 32 rows
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][0] + sb + 16 * s2 * ROWB));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][1] + sb + 16 * s2 * ROWB));
+                bf16x8& af = f[s2 * MT + mt];
+                af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+                af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+            }
+    };
+    auto load_consts = [&](f32x4 (&v)[4], int sb, int which) __attribute__((always_inline)) {  // which: 0 lse2, 1 delta
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = *(LDS_PTR(f32x4, ld_ptr + sb + 32 * g + 128 * which));
+    };
+    // Wait until only the newest AHEAD-2 staging requests of this wave are in flight, then the
+    // workgroup barrier.  (A plain __syncthreads() would wait for ALL of them: staging loads are
+    // pending LDS writes.)
     auto wait_and_barrier = [&](bool leave_newest) __attribute__((always_inline)) {
         if (leave_newest) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 2) * LPI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -255,102 +259,105 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     // prologue: slices 0 .. AHEAD-1 requested, 0 and 1 landed
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i)
-        if (i < niter) issue_dma_rt(i);
+        if (i < niter) issue_dma();
     wait_and_barrier(niter >= AHEAD);
 
-    // ---- the sweep, software-pipelined so that the matrix pipe has independent work while the
-    // vector pipe turns S into P and dP into dS (one wave per SIMD: nothing else would fill it):
-    //   dP'(it) = dO V^T - delta  | P(it) = exp2(c * S'(it))          S'(it) came from the previous iteration
-    //   dV     += dO^T P(it)      | dS(it) = P * dP' * scale
-    //   S'(it+1) = Q(it+1) K^T - lse / scale
-    //   dK     += Q^T dS(it)
+    // ---- the sweep.  One wave per SIMD: nothing but the wave's own instruction stream can keep
+    // the matrix pipe busy, so every product of 8 MFMAs runs on fragments that were read from LDS
+    // during the product before it, beside the vector work of its neighbours:
+    //   A  dP(it)   = dO V^T     | P = exp2(c S(it) - lse2)    | read dO^T(it), delta(it)
+    //   B  dV      += dO^T P     | dS = P (dP - delta)         | read Q(it+1) rows
+    //   C  S(it+1)  = Q K^T      | next staging request        | read Q^T(it)
+    //   D  dK      += Q^T dS     |                             | read dO(it+1) rows, lse2(it+1)
+    // (dS lacks the factor `scale`, which the epilogue applies to dK.)  Every wave computes every
+    // slice, also the few next to the diagonal that the mask empties for its keys: a second,
+    // shorter code path for them would make the compiler copy the 128 accumulator registers
+    // between the paths on every iteration.
     int c_sl = nslice - 1, c_hg = 0;  // (slice, head) being computed
-    if (niter > 0 && wave_active(c_sl * BQ)) compute_s(std::integral_constant<int, 0>{});
-    auto body = [&](int it, auto cur_c) __attribute__((always_inline)) {
-        constexpr int cur = decltype(cur_c)::value;
-        constexpr int nxt = (cur + 1) % NBUF, wr = (cur + AHEAD) % NBUF;
-        constexpr int QB = cur * SLOTB;          // Q of this slot
-        constexpr int OB = cur * SLOTB + QTILE;  // dO of this slot
+    int c_sb = 0;                     // byte offset of its ring slot
+    bf16x8 oa[KS];   // dO rows of the current slice
+    f32x4 l4[4];     // its lse2
+    f32x16 sv;       // its S
+    if (niter > 0) {
+        rescale_lse(0);
+        bf16x8 qa[KS];
+        load_rows(qa, 0);
+        load_rows(oa, QTILE);
+        load_consts(l4, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sv, 0, 0, 0);
+    }
+    for (int it = 0; it < niter; ++it) {
         const bool stage = (it + AHEAD < niter);
         const int i0 = c_sl * BQ;  // first query row of the slice, relative to q_row0
         if (++c_hg == p.group) { c_hg = 0; --c_sl; }
-        // slot `wr` held slice it-1, which every wave finished with before the last barrier
-        if (stage) issue_dma(std::integral_constant<int, wr>{});
-        const bool active = wave_active(i0);
-        const bool active_next = (it + 1 < niter) && wave_active(c_sl * BQ);
+        const int sb = c_sb;        // byte offset of this slice's slot
+        c_sb = (c_sb + SLOTB == NBUF * SLOTB) ? 0 : c_sb + SLOTB;
+        const int nsb = c_sb;       // and of the next slice's (after the last slice: a slot nobody reads any more)
+        const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+
+        // ---- A
+        bf16x8 ta[2 * MT];
+        f32x4 d4[4];
+        rescale_lse(nsb);
+        load_cols(ta, sb + QTILE);
+        load_consts(d4, sb, 1);
+        f32x16 dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa[ks], vf[ks], dp, 0, 0, 0);
+        float pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, -l4[i >> 2][i & 3]));
+        if (need_mask) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
+                pv[i] = dead ? 0.f : pv[i];
+                asm volatile("" : "+v"(pv[i]));  // keeps this a branch: as selects it would run for every slice
+            }
+        }
         bf16x8 pf[2];
-        if (active) {
-            const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
-            // dP' = dO V^T - delta (matrix pipe) beside P = exp2(c * S') (vector pipe)
-            f32x16 dp;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 d4 = *(LDS_PTR(f32x4, ld_ptr + QB + 32 * g + 128));
+        for (int i = 0; i < 16; ++i) pf[i >> 3][i & 7] = (__bf16)pv[i];
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- B
+        bf16x8 qa[KS];
+        load_rows(qa, nsb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dp[4 * g + e] = -d4[e];
-            }
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bf16x8 oa = *(LDS_PTR(bf16x8, a_ptr[ks] + OB));
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ks], dp, 0, 0, 0);
-            }
+            for (int mt = 0; mt < MT; ++mt) dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[s2 * MT + mt], pf[s2], dv[mt], 0, 0, 0);
+        bf16x8 dsf[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float pv = fast_exp2(sv[i] * c);
-                if (need_mask) {
-                    int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    bool dead = (kj > ii + shift) || (ii >= q_len) || (kj >= k_rows);
-                    pv = dead ? 0.f : pv;
-                }
-                pf[i >> 3][i & 7] = (__bf16)pv;
-            }
-            // dV^T += dO^T P (matrix pipe) beside dS = P * dP' * scale (vector pipe)
-            bf16x8 dsf[2];
+        for (int i = 0; i < 16; ++i) dsf[i >> 3][i & 7] = (__bf16)(pv[i] * (dp[i] - d4[i >> 2][i & 3]));
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- C
+        load_cols(ta, sb);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+        for (int i = 0; i < 16; ++i) sv[i] = 0.f;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][0] + OB + 16 * s2 * ROWB));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][1] + OB + 16 * s2 * ROWB));
-                    bf16x8 af;
-                    af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-                    af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-                    dv[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[s2], dv[mt], 0, 0, 0);
-                }
+        for (int ks = 0; ks < KS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sv, 0, 0, 0);
+        // the slot this request goes to held slice it-1, which every wave finished with before the last barrier
+        if (stage) issue_dma();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- D
+        load_rows(oa, nsb + QTILE);
+        load_consts(l4, nsb, 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float pb = (float)pf[i >> 3][i & 7];  // the rounded P, as dV saw it
-                dsf[i >> 3][i & 7] = (__bf16)(pb * dp[i] * p.scale);
-            }
-            pf[0] = dsf[0];
-            pf[1] = dsf[1];
-        }
-        // S' of the next slice: independent of everything above, keeps the matrix pipe busy while dS is formed
-        if (active_next) compute_s(std::integral_constant<int, nxt>{});
-        if (active) {
-            // dK^T += Q^T dS
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][0] + QB + 16 * s2 * ROWB));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][1] + QB + 16 * s2 * ROWB));
-                    bf16x8 af;
-                    af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-                    af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-                    dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[s2], dk[mt], 0, 0, 0);
-                }
-        }
-        // slice it+2 must have landed before the next iteration reads it for S'; the requests
-        // issued after it (it+3 .. it+AHEAD) stay in flight across the barrier
+            for (int mt = 0; mt < MT; ++mt) dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[s2 * MT + mt], dsf[s2], dk[mt], 0, 0, 0);
+        // slice it+2 must have landed before the next iteration reads it; the requests issued
+        // after it (it+3 .. it+AHEAD) stay in flight across the barrier
         wait_and_barrier(stage);
-    };
-    static_assert(NBUF == 4, "the loop below is unrolled over a ring of 4 slots");
-    for (int it = 0; it < niter; it += 4) {
-        body(it, std::integral_constant<int, 0>{});
-        if (it + 1 < niter) body(it + 1, std::integral_constant<int, 1>{});
-        if (it + 2 < niter) body(it + 2, std::integral_constant<int, 2>{});
-        if (it + 3 < niter) body(it + 3, std::integral_constant<int, 3>{});
     }
 
     // ---- epilogue: dK^T / dV^T accumulators (key on the lane) -> rows of dk / dv
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
                     float* dvp = reinterpret_cast<float*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
                     f32x4 a = *reinterpret_cast<f32x4*>(dkp), b = *reinterpret_cast<f32x4*>(dvp);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[e] += dk[mt][4 * g4 + e]; b[e] += dv[mt][4 * g4 + e]; }
+                    for (int e = 0; e < 4; ++e) { a[e] += dk[mt][4 * g4 + e] * p.scale; b[e] += dv[mt][4 * g4 + e]; }
                     *reinterpret_cast<f32x4*>(dkp) = a;
                     *reinterpret_cast<f32x4*>(dvp) = b;
                 } else {
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
                     __bf16* dvp = reinterpret_cast<__bf16*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
                     bf16x4 a, b;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[e] = (__bf16)dk[mt][4 * g4 + e]; b[e] = (__bf16)dv[mt][4 * g4 + e]; }
+                    for (int e = 0; e < 4; ++e) { a[e] = (__bf16)(dk[mt][4 * g4 + e] * p.scale); b[e] = (__bf16)dv[mt][4 * g4 + e]; }
                     *reinterpret_cast<bf16x4*>(dkp) = a;
                     *reinterpret_cast<bf16x4*>(dvp) = b;
                 }
