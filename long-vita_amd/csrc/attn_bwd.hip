@@ -169,32 +169,46 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
         pch16[j] = (lds_offd<D>(row, lane % CPR) - row * ROWB);
         voff_full[j] = row * (int)(x_rs * 2) + pch16[j];
     }
-    const float* const ld_base = ((lane < 32) ? p.lse : p.delta) + q_row0;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds0);
     // Iteration order: query slices from the LAST one down to the first, and for each slice the
     // query heads of the group.  Key blocks of one sequence all end at the same query row, so
     // workgroups that start together read the same Q / dO rows at the same time (L2 reuse).
+    // The request stream walks (slice, head) pairs in the sweep's order; its source addresses move
+    // by a constant step from one request to the next (next head, or first head of the slice
+    // before), so they are kept as running pointers: no multiplications per request.
     int ld_sl = nslice - 1, ld_hg = 0;  // (slice, head) of the next staging request
-    int ld_slot = 0;                    // ring slot it goes to
+    uint32_t ld_slot = lds_base;        // LDS byte address of the ring slot it goes to
+    const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
+    const int64_t x_step_head = x_hs * 2;
+    const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
+    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31
+    const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
+    const int64_t c_step_head = p.lse_stride;
+    const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
     auto issue_dma = [&]() __attribute__((always_inline)) {
-        const int sl = ld_sl, hg = ld_hg;
-        if (++ld_hg == p.group) { ld_hg = 0; --ld_sl; }
-        const uint32_t slot_base = lds_base + ld_slot * SLOTB;
-        if (++ld_slot == NBUF) ld_slot = 0;
-        const int head = kvh * p.group + hg;
-        const int rows_valid = min(BQ, q_len - sl * BQ);  // >= 1; rows past it repeat the last valid row
-        const __bf16* base = x_base + (int64_t)head * x_hs + (int64_t)sl * BQ * x_rs;
-        auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(base), 0, (uint32_t)((rows_valid - 1) * x_rs * 2 + ROWB), 0x00020000);
-        const uint32_t dst = slot_base + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
+        // only the last slice of the sequence (the first one requested) can be partial:
+        // rows past the end repeat the last valid row
+        const int rows_valid = (ld_sl == nslice - 1) ? q_len - ld_sl * BQ : BQ;
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ld_x), 0, (uint32_t)((rows_valid - 1) * x_rs * 2 + ROWB), 0x00020000);
+        const uint32_t dst = ld_slot + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
+        int voff[PPW];
+        const float* gp = ld_c;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            int voff = voff_full[j];
-            if (rows_valid < BQ) voff = min(prow0 + RPP * j, rows_valid - 1) * (int)(x_rs * 2) + pch16[j];
-            dma16_buffer(rs, voff, dst + j * 1024);
+        for (int j = 0; j < PPW; ++j) voff[j] = voff_full[j];
+        if (rows_valid < BQ) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) voff[j] = min(prow0 + RPP * j, rows_valid - 1) * (int)(x_rs * 2) + pch16[j];
+            gp += min(r, rows_valid - 1) - r;
         }
-        // lanes 0..31: lse of rows 0..31, lanes 32..63: delta of rows 0..31; every wave keeps its own copy
-        const float* gp = ld_base + (int64_t)head * p.lse_stride + sl * BQ + min(r, rows_valid - 1);
-        dma4_global(gp, slot_base + 2 * QTILE + w * 256);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) dma16_buffer(rs, voff[j], dst + j * 1024);
+        dma4_global(gp, ld_slot + 2 * QTILE + w * 256);  // every wave keeps its own copy
+        // advance to the next request
+        const bool wrap = (++ld_hg == p.group);
+        ld_x += wrap ? x_step_slice : x_step_head;
+        ld_c += wrap ? c_step_slice : c_step_head;
+        if (wrap) { ld_hg = 0; --ld_sl; }
+        ld_slot = (ld_slot + SLOTB == lds_base + NBUF * SLOTB) ? lds_base : ld_slot + SLOTB;
     };
 
     // ---- LDS read addresses in slot 0 (the slot offset is added per iteration, dO is an immediate)
