@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     // before), so they are kept as running pointers: no multiplications per request.
     int ld_sl = nslice - 1, ld_hg = 0;  // (slice, head) of the next staging request
     uint32_t ld_slot = lds_base;        // LDS byte address of the ring slot it goes to
+    int ld_n = 0;                       // requests issued so far
     const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
     const int64_t x_step_head = x_hs * 2;
     const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
@@ -185,29 +186,30 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
     const int64_t c_step_head = p.lse_stride;
     const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
+    // only the last slice of the sequence (the first one requested) can be partial: rows past the
+    // end repeat the last valid row
+    const int rows_last = q_len - (nslice - 1) * BQ;
+    int voff_part[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) voff_part[j] = min(prow0 + RPP * j, rows_last - 1) * (int)(x_rs * 2) + pch16[j];
+    const int c_part = min(r, rows_last - 1) - r;
     auto issue_dma = [&]() __attribute__((always_inline)) {
-        // only the last slice of the sequence (the first one requested) can be partial:
-        // rows past the end repeat the last valid row
-        const int rows_valid = (ld_sl == nslice - 1) ? q_len - ld_sl * BQ : BQ;
+        const bool partial = (ld_sl == nslice - 1);  // (a full last slice has voff_part == voff_full)
+        const int rows_valid = partial ? rows_last : BQ;
         auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ld_x), 0, (uint32_t)((rows_valid - 1) * x_rs * 2 + ROWB), 0x00020000);
         const uint32_t dst = ld_slot + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
-        int voff[PPW];
-        const float* gp = ld_c;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) voff[j] = voff_full[j];
-        if (rows_valid < BQ) {
-#pragma unroll
-            for (int j = 0; j < PPW; ++j) voff[j] = min(prow0 + RPP * j, rows_valid - 1) * (int)(x_rs * 2) + pch16[j];
-            gp += min(r, rows_valid - 1) - r;
-        }
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) dma16_buffer(rs, voff[j], dst + j * 1024);
-        dma4_global(gp, ld_slot + 2 * QTILE + w * 256);  // every wave keeps its own copy
-        // advance to the next request
-        const bool wrap = (++ld_hg == p.group);
-        ld_x += wrap ? x_step_slice : x_step_head;
-        ld_c += wrap ? c_step_slice : c_step_head;
-        if (wrap) { ld_hg = 0; --ld_sl; }
+        for (int j = 0; j < PPW; ++j) dma16_buffer(rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
+        dma4_global(ld_c + (partial ? c_part : 0), ld_slot + 2 * QTILE + w * 256);  // every wave keeps its own copy
+        // advance to the next request; past the last slice the stream stays where it is, so the
+        // loop's unconditional requests re-fetch that slice into a slot nobody reads any more
+        const bool adv = (++ld_n < niter);
+        const bool wrap = (ld_hg + 1 == p.group);
+        const int64_t xs = wrap ? x_step_slice : x_step_head, cs = wrap ? c_step_slice : c_step_head;
+        ld_x += adv ? xs : 0;
+        ld_c += adv ? cs : 0;
+        ld_hg = adv ? (wrap ? 0 : ld_hg + 1) : ld_hg;
+        ld_sl = (adv && wrap) ? ld_sl - 1 : ld_sl;
         ld_slot = (ld_slot + SLOTB == lds_base + NBUF * SLOTB) ? lds_base : ld_slot + SLOTB;
     };
 
@@ -265,16 +267,16 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
     // Wait until only the newest AHEAD-2 staging requests of this wave are in flight, then the
     // workgroup barrier.  (A plain __syncthreads() would wait for ALL of them: staging loads are
     // pending LDS writes.)
-    auto wait_and_barrier = [&](bool leave_newest) __attribute__((always_inline)) {
-        if (leave_newest) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 2) * LPI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    auto wait_and_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 2) * LPI) : "memory");
     };
 
     // prologue: slices 0 .. AHEAD-1 requested, 0 and 1 landed
+    if (niter > 0) {
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i)
-        if (i < niter) issue_dma();
-    wait_and_barrier(niter >= AHEAD);
+        for (int i = 0; i < AHEAD; ++i) issue_dma();
+        wait_and_barrier();
+    }
 
     // ---- the sweep.  One wave per SIMD: nothing but the wave's own instruction stream can keep
     // the matrix pipe busy, so every product of 8 MFMAs runs on fragments that were read from LDS
@@ -304,7 +306,6 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
         for (int ks = 0; ks < KS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sv, 0, 0, 0);
     }
     for (int it = 0; it < niter; ++it) {
-        const bool stage = (it + AHEAD < niter);
         const int i0 = c_sl * BQ;  // first query row of the slice, relative to q_row0
         if (++c_hg == p.group) { c_hg = 0; --c_sl; }
         const int sb = c_sb;        // byte offset of this slice's slot
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
         bf16x8 pf[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) pf[i >> 3][i & 7] = (__bf16)pv[i];
+        asm volatile("" : "+v"(pf[0]), "+v"(pf[1]));  // P is formed here, not next to its first use
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- B
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
         bf16x8 dsf[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dsf[i >> 3][i & 7] = (__bf16)(pv[i] * (dp[i] - d4[i >> 2][i & 3]));
+        asm volatile("" : "+v"(dsf[0]), "+v"(dsf[1]));  // dS is formed here, beside the dV products
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- C
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sv, 0, 0, 0);
         // the slot this request goes to held slice it-1, which every wave finished with before the last barrier
-        if (stage) issue_dma();
+        issue_dma();
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- D
@@ -371,8 +374,10 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
             for (int mt = 0; mt < MT; ++mt) dk[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[s2 * MT + mt], dsf[s2], dk[mt], 0, 0, 0);
         // slice it+2 must have landed before the next iteration reads it; the requests issued
         // after it (it+3 .. it+AHEAD) stay in flight across the barrier
-        wait_and_barrier(stage);
+        wait_and_barrier();
     }
+    // no staging request may outlive the workgroup: its LDS could already belong to another one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: dK^T / dV^T accumulators (key on the lane) -> rows of dk / dv
     if (kj < k_rows) {
