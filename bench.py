@@ -119,6 +119,22 @@ def cpu_baseline(seq, rows=1024, heads=(0, 1)):
                       f"{dt:.2f}s measured, extrapolated linearly in rows x heads"}
 
 
+def profiled_traffic(summary_name, kernel):
+    """Memory-side bytes per launch of `kernel`, from the committed rocprofv3 PMC passes of this same
+    command (profiles/<summary_name>; collected with tools_prof.sh in separate --pmc runs).
+    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
+    coalesced reads at 64 bytes, so it is doubled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", summary_name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        fetch = next(v["per_dispatch"] for k, v in d.items() if kernel in k and k.endswith("|FETCH_SIZE"))
+        write = next(v["per_dispatch"] for k, v in d.items() if kernel in k and k.endswith("|WRITE_SIZE"))
+    except (OSError, StopIteration, KeyError, ValueError):
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, f"bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from profiles/{summary_name}"
+
+
 def main():
     args = parse()
     rank, world, local = dist_setup(args.gpus)
@@ -235,16 +251,22 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         achieved = flops_per_gpu_step / mean_kernel_s / 1e12
+        traffic, traffic_note = None, None
+        if wl == "prefill_1m" and not args.seq and world == 1:
+            traffic, traffic_note = profiled_traffic("r01_prefill_1m_pmc_summary.json", "lv_fwd_kernel<128, true, 8>")
         res = {
-            "metric": "attention prefill tokens/sec (node) at 1M ctx" if wl == "prefill_1m" else f"attention tokens/sec ({wl})",
+            "metric": ("attention prefill tokens/sec (node) at 1M ctx" if not args.seq else f"attention prefill tokens/sec (node) at {S} ctx")
+            if wl == "prefill_1m" else f"attention tokens/sec ({wl})",
             "value": tokens_per_step * args.steps / dt, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": config,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "algorithmic FLOPs per GPU per step / mean device time per step (HIP events on the launch stream)"},
         }
+        if traffic_note:
+            res["roofline"]["traffic_note"] = traffic_note
         if not args.no_cpu_baseline and wl == "prefill_1m":
             res["cpu_baseline"] = cpu_baseline(config["seq_len"])
         print(json.dumps(res), flush=True)
