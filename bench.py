@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line: metric tokens/s for the whole job, plus
   cpu_baseline the reference's eager PyTorch attention (oracle restatement)
                timed on the host cores on a bounded row sample, extrapolated.
 
-Other workloads (``cfg3_fwd_bwd``: 128K packed tokens forward+backward;
+Other workloads (``cfg3_fwd_bwd``: 128K packed tokens forward+backward; ``rope_qk``: rotary embedding of Q and K;
 ``cfg2_vit``: InternViT-300M attention on 64 frames) are for profiling; the
 judged line is the default one.
 """
@@ -39,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (spec), TFLOP/s
+PEAK_HBM_GBS = 8000.0       # MI355X HBM3E peak (spec), GB/s
 HQ, HKV, D = 40, 8, 128
 
 
@@ -47,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit"])
+    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "rope_qk"])
     ap.add_argument("--seq", type=int, default=0, help="override the sequence length (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -216,6 +217,26 @@ def main():
         config = {"workload": f"{wl}: varlen causal attention fwd+bwd, {len(lens)} segment(s)", "seq_len": S, "q_heads": HQ, "kv_heads": HKV,
                   "head_dim": D, "parallelism": "cp1"}
         scaling = "weak"
+    elif wl == "rope_qk":  # rotary embedding of one layer's Q and K at 128K tokens, in place (bandwidth-bound)
+        S = args.seq or 131072
+        q, k = rnd(S, HQ, D), rnd(S, HKV, D)
+        inv = 1.0 / (1000000 ** (torch.arange(0, D, 2, dtype=torch.float32, device=dev) / D))
+        ang = torch.outer(torch.arange(S, device=dev, dtype=torch.float32), inv)
+        ang = torch.cat((ang, ang), -1)
+        cos_t, sin_t = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+
+        def step():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.rope_launch(q, cos_t, sin_t, out=q)
+            ops.rope_launch(k, cos_t, sin_t, out=k)
+            e1.record()
+            return e0, e1
+        tokens_per_step = S
+        hbm_bytes_per_step = 2.0 * S * (HQ + HKV) * D * 2 + 2.0 * 2 * S * D * 2   # x read + written; both tables once per tensor
+        flops_per_step = flops_per_gpu_step = 0.0
+        config = {"workload": "rope_qk: rotary embedding of Q [S,40,128] and K [S,8,128], in place", "seq_len": S}
+        scaling = "weak"
     else:  # cfg2_vit: 24 layers x 64 frames x 16 heads x 1025 tokens, d=64, non-causal
         B, H, Sv, Dv, layers = 64, 16, 1025, 64, 24
         qkv = [rnd(Sv, B * H, Dv) for _ in range(3)]
@@ -265,6 +286,10 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "algorithmic FLOPs per GPU per step / mean device time per step (HIP events on the launch stream)"},
         }
+        if wl == "rope_qk":
+            gbs = hbm_bytes_per_step / mean_kernel_s / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                               "traffic": None, "note": "algorithmic bytes per step / mean device time per step"}
         if traffic_note:
             res["roofline"]["traffic_note"] = traffic_note
         if not args.no_cpu_baseline and wl == "prefill_1m":

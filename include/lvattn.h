@@ -157,6 +157,22 @@ int lv_scatter_rows(const void* src, void* dst, const int64_t* src_index, const 
 int lv_gather_rows(const void* src, void* dst, const int64_t* index, int64_t n,
                    int64_t row_bytes, int64_t src_rows, void* stream);
 
+/* ---- rotary position embedding ---------------------------------------------------
+ * lv_rope: apply_rotary_pos_emb_bshd / apply_rotary_pos_emb_thd
+ * (lcvlm_modellink/core/models/common/embeddings/rotary_pos_embedding.py:181-204, 207-229; called on
+ * query and key by Megatron's SelfAttention ahead of flash_attention_forward), non-interleaved form.
+ * x / out [rows, heads, d] bf16 with row and head strides (out may alias x); the first `rot` columns are
+ * rotated, the rest copied.  cos_tab / sin_tab [tab_rows, rot] bf16: cos and sin of the angle table
+ * RotaryEmbedding.forward builds (:84-122), rounded to bf16 as :200-201 does.  The table row of a tensor
+ * row is pos_ids[row] when pos_ids is given (packed sequences: positions restart per sample, :114-117 /
+ * the per-segment freqs[:len] of :223-229), else row / tab_div (tab_div = batch size when the table has
+ * one row per sequence position of an [s, b, h, d] tensor).  Every product and the sum round to bf16 as
+ * the reference's eager ops do; conj != 0 applies the transposed rotation (the gradient). */
+int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, const int32_t* pos_ids,
+            int64_t rows, int heads, int d, int rot,
+            int64_t x_row_stride, int64_t x_head_stride, int64_t o_row_stride, int64_t o_head_stride,
+            int64_t tab_rows, int tab_div, int conj, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

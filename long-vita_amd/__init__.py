@@ -9,6 +9,7 @@ Sub-modules
   cp_partition            zig-zag batch slicing, image index remap, un-zig-zag
   packing                 sample packing -> actual_seq_len / image indices
   vision                  pixel-shuffle token compression, feature scatter
+  rotary_pos_embedding    RotaryEmbedding angle tables, apply_rotary_pos_emb on the HIP kernel
   state                   the ambient state the reference reads (args, actual_seq_len, CP group)
 """
 __version__ = "0.1.0"

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "lv_pixel_shuffle": (_int, [_vp, _vp, _int, _int, _int, _int, _i64, _vp]),
     "lv_scatter_rows": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp]),
     "lv_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "lv_rope": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

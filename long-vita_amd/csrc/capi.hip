@@ -388,3 +388,24 @@ extern "C" int lv_gather_rows(const void* src, void* dst, const int64_t* index, 
     if (!index) return fail(LV_EINVAL, "index is null");
     return move_rows(src, dst, index, nullptr, n, row_bytes, src_rows, n, stream);
 }
+
+// ---------------------------------------------------------------------------
+// rotary position embedding
+// ---------------------------------------------------------------------------
+extern "C" int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, const int32_t* pos_ids,
+                       int64_t rows, int heads, int d, int rot, int64_t x_row_stride, int64_t x_head_stride,
+                       int64_t o_row_stride, int64_t o_head_stride, int64_t tab_rows, int tab_div, int conj, void* stream) {
+    if (!x || !out || !cos_tab || !sin_tab) return fail(LV_EINVAL, "lv_rope: null pointer");
+    if (rows < 0 || heads <= 0) return fail(LV_EINVAL, "lv_rope: rows=%lld heads=%d", (long long)rows, heads);
+    if (d <= 0 || d % 8 || rot <= 0 || rot > d || rot % 16)
+        return fail(LV_EINVAL, "lv_rope: d=%d rot=%d (need d %% 8 == 0, rot %% 16 == 0, 0 < rot <= d)", d, rot);
+    if (tab_rows <= 0 || tab_div <= 0) return fail(LV_EINVAL, "lv_rope: tab_rows=%lld tab_div=%d", (long long)tab_rows, tab_div);
+    if (!pos_ids && rows > 0 && (rows - 1) / tab_div >= tab_rows)
+        return fail(LV_EINVAL, "lv_rope: %lld rows / %d need more than the table's %lld rows", (long long)rows, tab_div, (long long)tab_rows);
+    if (x_row_stride % 8 || x_head_stride % 8 || o_row_stride % 8 || o_head_stride % 8 ||
+        ((uintptr_t)x | (uintptr_t)out | (uintptr_t)cos_tab | (uintptr_t)sin_tab) % 16)
+        return fail(LV_EINVAL, "lv_rope: rows, heads and tables must be 16-byte aligned");
+    int rc = lv_launch_rope(x, out, cos_tab, sin_tab, pos_ids, rows, heads, d, rot, x_row_stride, x_head_stride, o_row_stride,
+                            o_head_stride, tab_rows, tab_div, conj, (hipStream_t)stream);
+    return rc ? fail(LV_ELAUNCH, "lv_rope: launch failed") : LV_OK;
+}

@@ -38,3 +38,6 @@ struct BwdParams {
 int lv_launch_bwd(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);
 int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows, int hq, int d, int64_t o_rs, int64_t o_hs,
                         int64_t do_rs, int64_t do_hs, int64_t lse_stride, hipStream_t stream);
+int lv_launch_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, const int32_t* pos_ids, int64_t rows,
+                   int heads, int d, int rot, int64_t x_rs, int64_t x_hs, int64_t o_rs, int64_t o_hs, int64_t tab_rows, int tab_div,
+                   int conj, hipStream_t stream);

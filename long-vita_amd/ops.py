@@ -274,3 +274,53 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     check(_lib.lib().lv_gather_rows(_ptr(src), _ptr(out), _ptr(index), index.numel(), row_bytes, src.shape[0], _stream()),
           "lv_gather_rows")
     return out
+
+
+# ---------------------------------------------------------------------------
+# rotary position embedding
+# ---------------------------------------------------------------------------
+def rope_launch(x: torch.Tensor, cos_tab: torch.Tensor, sin_tab: torch.Tensor, pos_ids: torch.Tensor | None = None,
+                tab_div: int = 1, conj: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """x [rows, heads, d] bf16 (last dim contiguous) -> rotated copy (or in place when out is x).
+    cos_tab / sin_tab [tab_rows, rot] bf16 contiguous; table row = pos_ids[row] (int32) or row // tab_div."""
+    _require_gpu(x, cos_tab, sin_tab)
+    if x.dtype != torch.bfloat16 or cos_tab.dtype != torch.bfloat16 or sin_tab.dtype != torch.bfloat16:
+        raise LvAttnError("rope_launch expects bfloat16 tensors and tables")
+    if x.dim() != 3:
+        raise LvAttnError("rope_launch expects [rows, heads, d]")
+    x = _last_contig(x)
+    cos_tab, sin_tab = cos_tab.contiguous(), sin_tab.contiguous()
+    if cos_tab.shape != sin_tab.shape or cos_tab.dim() != 2:
+        raise LvAttnError("cos / sin tables must be [tab_rows, rot] of one shape")
+    rows, heads, d = x.shape
+    tab_rows, rot = cos_tab.shape
+    if out is None:
+        out = torch.empty((rows, heads, d), dtype=x.dtype, device=x.device)
+    if pos_ids is not None:
+        _require_gpu(pos_ids)
+        if pos_ids.dtype != torch.int32 or pos_ids.numel() != rows or not pos_ids.is_contiguous():
+            raise LvAttnError("pos_ids must be a contiguous int32 tensor with one entry per row")
+    check(_lib.lib().lv_rope(_ptr(x), _ptr(out), _ptr(cos_tab), _ptr(sin_tab), _ptr(pos_ids), rows, heads, d, rot,
+                             x.stride(0), x.stride(1), out.stride(0), out.stride(1), tab_rows, int(tab_div), int(bool(conj)),
+                             _stream()), "lv_rope")
+    return out
+
+
+class _Rope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cos_tab, sin_tab, pos_ids, tab_div):
+        ctx.save_for_backward(cos_tab, sin_tab, pos_ids if pos_ids is not None else torch.empty(0))
+        ctx.has_pos = pos_ids is not None
+        ctx.tab_div = tab_div
+        return rope_launch(x, cos_tab, sin_tab, pos_ids, tab_div, conj=False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        cos_tab, sin_tab, pos = ctx.saved_tensors
+        dx = rope_launch(dout, cos_tab, sin_tab, pos if ctx.has_pos else None, ctx.tab_div, conj=True)
+        return dx, None, None, None, None
+
+
+def rope(x: torch.Tensor, cos_tab: torch.Tensor, sin_tab: torch.Tensor, pos_ids: torch.Tensor | None = None, tab_div: int = 1):
+    """Differentiable rotary embedding of x [rows, heads, d] (see rope_launch)."""
+    return _Rope.apply(x, cos_tab, sin_tab, pos_ids, int(tab_div))

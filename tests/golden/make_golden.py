@@ -22,6 +22,8 @@ Fixtures written:
                        (pretrain_lcvlm.py), get_pos_emb_on_this_cp_rank
                        (rotary_pos_embedding.py)
   packing.npz          Qwen2Dataset.add_ret / process_ret (cognitron_vl/data/dataset_qwen2.py)
+  rope.npz             RotaryEmbedding.forward angle tables (incl. packed position ids),
+                       apply_rotary_pos_emb_bshd / _thd on bf16 tensors (rotary_pos_embedding.py)
 """
 from __future__ import annotations
 
@@ -310,8 +312,77 @@ def gen_packing():
     print("packing.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------
+def gen_rope():
+    """RotaryEmbedding.forward (angle table, packed position-id gather) and the eager appliers
+    apply_rotary_pos_emb_bshd / _thd of rotary_pos_embedding.py, on bf16 inputs as the model runs them."""
+    rope = importlib.import_module("lcvlm_modellink.core.models.common.embeddings.rotary_pos_embedding")
+    out = {}
+    saved_dev = torch.cuda.current_device
+    torch.cuda.current_device = lambda: "cpu"
+    try:
+        g = torch.Generator().manual_seed(77)
+        # ---- angle tables: Qwen2.5 shape (d=128, base 1e6) and a small one
+        for tag, d, base, n in (("qwen", 128, 1000000, 4096), ("small", 16, 10000, 40)):
+            re = rope.RotaryEmbedding(d, 1.0, rotary_interleaved=False, rotary_base=base)
+            rope.parallel_state = ns(get_context_parallel_world_size=lambda: 1, get_context_parallel_rank=lambda: 0)
+            rope.get_position_ids = lambda: None
+            emb = re.forward(n)
+            out[f"table.{tag}.inv_freq"] = re.inv_freq.numpy()
+            out[f"table.{tag}.emb"] = emb.numpy() if n <= 64 else emb[:: n // 32].numpy()  # a row sample of the big one
+            out[f"table.{tag}.meta"] = np.array([d, base, n], dtype=np.int64)
+        # packed sequences: position ids restart per sample ([s, b] as mindspeed hands them over)
+        re = rope.RotaryEmbedding(16, 1.0, rotary_interleaved=False, rotary_base=10000)
+        pos = torch.tensor([[0, 1, 2, 3, 4, 0, 1, 2, 0, 1, 2, 3, 4, 5, 6, 7]], dtype=torch.int64).t().contiguous()  # [16, 1]
+        rope.get_position_ids = lambda: pos
+        out["table.packed.pos"] = pos.numpy()
+        out["table.packed.emb"] = re.forward(16).numpy()
+        rope.get_position_ids = lambda: None
+
+        # ---- appliers on bf16 tensors
+        for tag, s, b, h, d, base in (("a", 24, 2, 3, 16, 10000), ("b", 96, 1, 5, 128, 1000000), ("c", 33, 1, 2, 64, 10000)):
+            re = rope.RotaryEmbedding(d, 1.0, rotary_interleaved=False, rotary_base=base)
+            freqs = re.forward(s)  # [s, 1, 1, d] fp32
+            t = (torch.randn(s, b, h, d, generator=g) * 1.5).to(torch.bfloat16).requires_grad_(True)
+            o = rope.apply_rotary_pos_emb_bshd(t, freqs, rotary_interleaved=False)
+            do = torch.randn(s, b, h, d, generator=g).to(torch.bfloat16)
+            o.backward(do)
+            out[f"bshd.{tag}.t"] = t.detach().float().numpy()
+            out[f"bshd.{tag}.freqs"] = freqs.numpy()
+            out[f"bshd.{tag}.out"] = o.detach().float().numpy()
+            out[f"bshd.{tag}.dout"] = do.float().numpy()
+            out[f"bshd.{tag}.dt"] = t.grad.float().numpy()  # torch autograd through the reference's eager ops
+            assert o.dtype == torch.bfloat16 and t.grad.dtype == torch.bfloat16
+        # partial rotary dimension (rot_dim < d passes the tail through)
+        re = rope.RotaryEmbedding(32, 0.5, rotary_interleaved=False, rotary_base=10000)
+        freqs = re.forward(12)
+        t = torch.randn(12, 1, 2, 32, generator=g).to(torch.bfloat16)
+        out["bshd.partial.t"] = t.float().numpy()
+        out["bshd.partial.freqs"] = freqs.numpy()
+        out["bshd.partial.out"] = rope.apply_rotary_pos_emb_bshd(t, freqs).float().numpy()
+        # thd (packed): positions restart at every cu_seqlens boundary
+        re = rope.RotaryEmbedding(64, 1.0, rotary_interleaved=False, rotary_base=1000000)
+        freqs = re.forward(40)
+        cu = torch.tensor([0, 7, 7 + 19, 7 + 19 + 1, 40], dtype=torch.int32)
+        t = torch.randn(40, 4, 64, generator=g).to(torch.bfloat16)
+        out["thd.t"] = t.float().numpy()
+        out["thd.cu"] = cu.numpy()
+        out["thd.freqs"] = freqs.numpy()
+        out["thd.out"] = rope.apply_rotary_pos_emb_thd(t, cu, freqs).float().numpy()
+    finally:
+        torch.cuda.current_device = saved_dev
+    np.savez_compressed(os.path.join(HERE, "rope.npz"), **out)
+    print("rope.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     install_shim()
-    gen_eager_attention()
-    gen_indexing()
-    gen_packing()
+    which = sys.argv[1:] or ["eager", "indexing", "packing", "rope"]
+    if "eager" in which:
+        gen_eager_attention()
+    if "indexing" in which:
+        gen_indexing()
+    if "packing" in which:
+        gen_packing()
+    if "rope" in which:
+        gen_rope()

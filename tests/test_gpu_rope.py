@@ -1,0 +1,123 @@
+"""Rotary position embedding: the HIP kernel (through the C ABI) against the oracle and the
+reference-made fixture.  Bit-exact: the kernel reproduces the reference's bf16 rounding sequence."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rope_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(golden_dir):
+    return np.load(os.path.join(golden_dir, "rope.npz"))
+
+
+def _tables(freqs_np):
+    """cos / sin bf16 tables computed by the ORACLE (numpy), so the comparison isolates the kernel."""
+    rot = freqs_np.shape[-1]
+    flat = freqs_np.reshape(-1, rot).astype(np.float32)
+    cos_t = torch.from_numpy(R.bf16_round(np.cos(flat, dtype=np.float32))).to(torch.bfloat16).cuda()
+    sin_t = torch.from_numpy(R.bf16_round(np.sin(flat, dtype=np.float32))).to(torch.bfloat16).cuda()
+    return cos_t, sin_t
+
+
+def _bf(x):
+    return torch.from_numpy(x).to(torch.bfloat16).cuda()
+
+
+def test_kernel_bit_exact_on_reference_fixture(golden_dir):
+    from long_vita_amd import ops
+    g = _g(golden_dir)
+    for tag in ("a", "b", "c", "partial"):
+        t, freqs = g[f"bshd.{tag}.t"], g[f"bshd.{tag}.freqs"]
+        s, b, h, d = t.shape
+        cos_t, sin_t = _tables(freqs)
+        out = ops.rope_launch(_bf(t).view(s * b, h, d), cos_t, sin_t, None, b)
+        assert np.array_equal(out.float().cpu().numpy().reshape(t.shape), g[f"bshd.{tag}.out"]), tag
+        if f"bshd.{tag}.dt" in g.files:
+            dt = ops.rope_launch(_bf(g[f"bshd.{tag}.dout"]).view(s * b, h, d), cos_t, sin_t, None, b, conj=True)
+            assert np.array_equal(dt.float().cpu().numpy().reshape(t.shape), g[f"bshd.{tag}.dt"]), tag
+    # packed: positions restart per segment
+    cos_t, sin_t = _tables(g["thd.freqs"])
+    pos = torch.from_numpy(R.thd_position_ids(g["thd.cu"]).astype(np.int32)).cuda()
+    out = ops.rope_launch(_bf(g["thd.t"]), cos_t, sin_t, pos, 1)
+    assert np.array_equal(out.float().cpu().numpy(), g["thd.out"])
+
+
+def test_kernel_vs_oracle_qwen_shape_strided_and_in_place():
+    """Qwen2.5 head shape, q and k as strided views of one fused qkv buffer, in-place rotation."""
+    from long_vita_amd import ops
+    rs = np.random.RandomState(5)
+    S, HQ, HKV, D = 777, 40, 8, 128
+    freqs = R.angle_table(S, D, 1000000)
+    cos_t, sin_t = _tables(freqs)
+    qkv = torch.from_numpy(rs.randn(S, (HQ + 2 * HKV) * D).astype(np.float32)).to(torch.bfloat16).cuda()
+    q = qkv[:, : HQ * D].view(S, HQ, D)
+    k = qkv[:, HQ * D:(HQ + HKV) * D].view(S, HKV, D)
+    want_q = R.apply_bshd(q.float().cpu().numpy()[:, None], freqs)[:, 0]
+    want_k = R.apply_bshd(k.float().cpu().numpy()[:, None], freqs)[:, 0]
+    v_before = qkv[:, (HQ + HKV) * D:].clone()
+    ops.rope_launch(q, cos_t, sin_t, out=q)
+    ops.rope_launch(k, cos_t, sin_t, out=k)
+    assert np.array_equal(q.float().cpu().numpy(), want_q)
+    assert np.array_equal(k.float().cpu().numpy(), want_k)
+    assert torch.equal(qkv[:, (HQ + HKV) * D:], v_before)      # v untouched
+
+
+def test_autograd_and_reference_api(golden_dir):
+    """apply_rotary_pos_emb (the reference's entry point): forward and gradient against the fixture.
+    The tables come from torch's device cos / sin here, so allow the last bf16 bit of cos / sin to differ:
+    at most a few elements may move by one bf16 step."""
+    from types import SimpleNamespace
+    from long_vita_amd.rotary_pos_embedding import apply_rotary_pos_emb
+    g = _g(golden_dir)
+    cfg = SimpleNamespace(rotary_interleaved=False, apply_rope_fusion=True)
+    for tag in ("a", "b", "c"):
+        t = _bf(g[f"bshd.{tag}.t"]).requires_grad_(True)
+        freqs = torch.from_numpy(g[f"bshd.{tag}.freqs"]).cuda()
+        out = apply_rotary_pos_emb(t, freqs, cfg)
+        out.backward(_bf(g[f"bshd.{tag}.dout"]))
+        for got, want in ((out, g[f"bshd.{tag}.out"]), (t.grad, g[f"bshd.{tag}.dt"])):
+            got = got.detach().float().cpu().numpy()
+            scale = np.maximum(np.abs(want), 1e-3)
+            assert np.max(np.abs(got - want) / scale) <= 2.0 ** -6, tag     # <= 2 bf16 steps
+            assert np.mean(got != want) < 0.02, tag
+    t = _bf(g["thd.t"])
+    out = apply_rotary_pos_emb(t, torch.from_numpy(g["thd.freqs"]).cuda(), cfg, cu_seqlens=torch.from_numpy(g["thd.cu"]).cuda())
+    got, want = out.float().cpu().numpy(), g["thd.out"]
+    assert np.mean(got != want) < 0.02 and np.max(np.abs(got - want)) <= 2.0 ** -6 * np.max(np.abs(want))
+
+
+def test_rope_rotation_properties_at_full_size():
+    """131072 rows x 40 heads x 128 (cfg3 size): conj(rope(x)) returns x up to bf16 rounding, row norms
+    are preserved, and position 0 is the identity."""
+    from long_vita_amd import ops
+    S, H, D = 131072, 40, 128
+    torch.manual_seed(0)
+    x = torch.randn(S, H, D, device="cuda", dtype=torch.bfloat16)
+    inv = 1.0 / (1000000 ** (torch.arange(0, D, 2, dtype=torch.float32, device="cuda") / D))
+    ang = torch.outer(torch.arange(S, device="cuda", dtype=torch.float32), inv)
+    ang = torch.cat((ang, ang), -1)
+    cos_t, sin_t = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+    y = ops.rope_launch(x, cos_t, sin_t)
+    assert torch.equal(y[0], x[0])
+    back = ops.rope_launch(y, cos_t, sin_t, conj=True)
+    err = (back.float() - x.float()).abs().max().item()
+    assert err <= 0.08, err          # three bf16 roundings each way on |x| <= ~5
+    n0 = x[::997].float().norm(dim=-1)
+    n1 = y[::997].float().norm(dim=-1)
+    assert torch.allclose(n0, n1, rtol=1e-2)
+
+
+def test_rope_argument_errors():
+    from long_vita_amd import _lib, ops
+    x = torch.zeros(8, 2, 64, device="cuda", dtype=torch.bfloat16)
+    tab = torch.zeros(4, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(_lib.LvAttnError):    # 8 rows, table of 4
+        ops.rope_launch(x, tab, tab)
+    with pytest.raises(_lib.LvAttnError):    # rotary width not a multiple of 16
+        ops.rope_launch(x, tab[:, :24].contiguous(), tab[:, :24].contiguous(), None, 2)
+    ops.rope_launch(x, tab, tab, None, 2)     # 8 rows / 2 = 4 table rows: fine
