@@ -10,11 +10,15 @@ from __future__ import annotations
 from . import state
 from .core_attention import (do_ring_context_parallel, dot_product_attention_forward_wrapper, flash_attention_forward)
 from .ring_context_parallel import ringattn_context_parallel
+from .rotary_pos_embedding import RotaryEmbedding, apply_rotary_pos_emb
 
 PATCHES = {
     "modellink.core.transformer.dot_product_attention.flash_attention_forward": flash_attention_forward,
     "modellink.core.transformer.dot_product_attention.do_ring_context_parallel": do_ring_context_parallel,
     "mindspeed.core.context_parallel.ring_context_parallel.ringattn_context_parallel": ringattn_context_parallel,
+    # the dotted names the reference's own (commented-out) rotary patch uses, lcvlm_modellink/megatron_adaptor.py:92-93
+    "megatron.core.models.common.embeddings.rotary_pos_embedding.RotaryEmbedding": RotaryEmbedding,
+    "megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb": apply_rotary_pos_emb,
 }
 
 
