@@ -25,10 +25,17 @@ extern "C" int lvattn_abi_version(void) { return 1; }
 
 // Query rows per forward work item.  256 (8 waves per workgroup) by default; the
 // environment variable LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
+static bool fwd_pingpong() {
+    static bool v = [] {
+        const char* e = getenv("LVATTN_FWD_KERNEL");
+        return e && !strcmp(e, "pp");
+    }();
+    return v;
+}
 static int fwd_waves() {
     static int w = [] {
         const char* e = getenv("LVATTN_FWD_WAVES");
-        return (e && atoi(e) == 4) ? 4 : 8;
+        return (e && atoi(e) == 4 && !fwd_pingpong()) ? 4 : 8;
     }();
     return w;
 }
@@ -159,7 +166,7 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
     p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
     p.o_rs = o_rs; p.o_hs = o_hs; p.lse_stride = lse_stride;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (fwd_pingpong() ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream) : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }
 

@@ -15,6 +15,7 @@ struct FwdParams {
     float scale, scale_log2e;
 };
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
+int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
 
 #define LV_BWD_BLOCK_N_INTERNAL 128
 
