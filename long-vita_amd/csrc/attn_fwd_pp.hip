@@ -231,29 +231,57 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 
             // ================= MFMA(t+1): S_{t+1} = K_{t+1} Q^T, O += V_t P_t =================
             sb = (sb + SLOTB == NS * SLOTB) ? 0 : sb + SLOTB;
+            // Four groups of 8 MFMAs: group (st, s2) = MT products O += V[32st+16s2 .. +16]^T P[st][s2] and
+            // KS/2 steps of the S[st] chain.  The fragments of group g+1 are read from LDS while group g
+            // runs (two register sets), so that no MFMA waits for a read issued just before it.
+            bf16x8 vfr[2][MT], kfr[2][KS / 2];
+            auto load_group = [&](int g, int set) __attribute__((always_inline)) {
+                const int st = g >> 1, s2 = g & 1;
+                const int voff = sb + (32 * st + 16 * s2) * ROWB;
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+                for (int mt = 0; mt < MT; ++mt) {
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][0] + voff));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][1] + voff));
+                    bf16x8& vf = vfr[set][mt];
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[st][i] = 0.f;
+                for (int kk = 0; kk < KS / 2; ++kk)
+                    kfr[set][kk] = *(LDS_PTR(bf16x8, k_ptr[s2 * (KS / 2) + kk] + sb + st * 32 * ROWB));
+            };
+            constexpr int RPG = 2 * MT + KS / 2;  // LDS reads per group
+            constexpr int MPG = MT + KS / 2;      // MFMAs per group
+            load_group(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RPG, 0);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int voff = sb + (32 * st + 16 * s2) * ROWB;
+            for (int g = 0; g < 4; ++g) {
+                const int st = g >> 1, s2 = g & 1, set = g & 1;
+                if (g < 3) load_group(g + 1, set ^ 1);
+                if (s2 == 0) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][0] + voff));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][1] + voff));
-                        bf16x8 vf;
-                        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st][s2], oacc[mt], 0, 0, 0);
+                    for (int i = 0; i < 16; ++i) s[st][i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < MPG; ++i) {
+                    // alternate the two accumulation targets so that consecutive MFMAs are independent
+                    if (i % 2 == 0 && i / 2 < MT) oacc[i / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[set][i / 2], pf[st][s2], oacc[i / 2], 0, 0, 0);
+                    else if (i % 2 == 1 && i / 2 < KS / 2) s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[set][i / 2], qf[s2 * (KS / 2) + i / 2], s[st], 0, 0, 0);
+                    else if (i / 2 >= KS / 2) oacc[i - KS / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[set][i - KS / 2], pf[st][s2], oacc[i - KS / 2], 0, 0, 0);
+                    else s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[set][i - MT], qf[s2 * (KS / 2) + i - MT], s[st], 0, 0, 0);
+                }
+                // issue order: the next group's reads spread between this group's MFMAs
+                if (g < 3) {
+                    static_assert(RPG * 2 == MPG * 3, "three reads per two MFMAs");
+#pragma unroll
+                    for (int i = 0; i < MPG / 2; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
-                    // the S chain of this sub-tile between the O products: no MFMA waits on the one before it
-#pragma unroll
-                    for (int kk = 0; kk < KS / 2; ++kk) {
-                        const int ks = s2 * (KS / 2) + kk;
-                        bf16x8 kf = *(LDS_PTR(bf16x8, k_ptr[ks] + sb + st * 32 * ROWB));
-                        s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
-                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
