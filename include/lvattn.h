@@ -47,8 +47,8 @@ extern "C" {
 
 /* Library identification / diagnostics. */
 int lvattn_abi_version(void);
-/* Query rows per forward work item (LV_FWD_BLOCK_M unless overridden by the environment
- * variable LVATTN_FWD_WAVES=4, which selects 128-row items). */
+/* Query rows per forward work item (LV_FWD_BLOCK_M unless the environment selects the 4-wave
+ * lockstep kernel with LVATTN_FWD_KERNEL=lockstep LVATTN_FWD_WAVES=4: then 128). */
 int lvattn_fwd_block_m(void);
 const char* lvattn_last_error(void);
 

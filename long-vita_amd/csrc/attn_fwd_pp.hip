@@ -21,6 +21,10 @@
 
 typedef __attribute__((address_space(3))) char lds_char;
 
+#ifndef LV_PP_PRIO
+#define LV_PP_PRIO 2   // s_setprio level of a wave in its matrix phase (0 in the vector phase)
+#endif
+
 template <int D>
 __device__ __forceinline__ int lds_off_pp(int row, int chunk) {
     if constexpr (D == 128) return lds_off128(row, chunk);
@@ -230,6 +234,9 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
             __builtin_amdgcn_sched_barrier(0);
 
             // ================= MFMA(t+1): S_{t+1} = K_{t+1} Q^T, O += V_t P_t =================
+            // The wave in its matrix phase outranks its SIMD partner (in its vector phase) at the issue
+            // port: an MFMA goes out the moment the pipe is free, the softmax fills the cycles between.
+            __builtin_amdgcn_s_setprio(LV_PP_PRIO);
             sb = (sb + SLOTB == NS * SLOTB) ? 0 : sb + SLOTB;
             // Four groups of 8 MFMAs: group (st, s2) = MT products O += V[32st+16s2 .. +16]^T P[st][s2] and
             // KS/2 steps of the S[st] chain.  The fragments of group g+1 are read from LDS while group g
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }

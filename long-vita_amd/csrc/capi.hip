@@ -23,19 +23,27 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" int lvattn_abi_version(void) { return 1; }
 
-// Query rows per forward work item.  256 (8 waves per workgroup) by default; the
-// environment variable LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
-static bool fwd_pingpong() {
-    static bool v = [] {
+// Forward kernel choice.  Default: the ping-pong kernel for head dim 128 and the lockstep kernel for
+// head dim 64 (each is the faster one there: +13 % at d = 128, -16 % at d = 64).  The environment variable
+// LVATTN_FWD_KERNEL=pp / lockstep forces one of them for every head dim.
+static int fwd_kernel_override() {   // 0 none, 1 ping-pong, 2 lockstep
+    static int v = [] {
         const char* e = getenv("LVATTN_FWD_KERNEL");
-        return e && !strcmp(e, "pp");
+        if (!e) return 0;
+        return !strcmp(e, "pp") ? 1 : (!strcmp(e, "lockstep") ? 2 : 0);
     }();
     return v;
 }
+static bool fwd_pingpong(int d) {
+    const int o = fwd_kernel_override();
+    return o == 1 || (o == 0 && d == 128);
+}
+// Query rows per forward work item: 256 (8 waves per workgroup); with the lockstep kernel forced,
+// LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
 static int fwd_waves() {
     static int w = [] {
         const char* e = getenv("LVATTN_FWD_WAVES");
-        return (e && atoi(e) == 4 && !fwd_pingpong()) ? 4 : 8;
+        return (e && atoi(e) == 4 && fwd_kernel_override() == 2) ? 4 : 8;
     }();
     return w;
 }
@@ -166,7 +174,7 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
     p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
     p.o_rs = o_rs; p.o_hs = o_hs; p.lse_stride = lse_stride;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (fwd_pingpong() ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream) : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream) : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }
 
