@@ -23,6 +23,8 @@
 // S and P are recomputed in both kernels (7 matrix products instead of 5); in exchange no
 // gradient is summed across workgroups, so results are bitwise reproducible.
 #include "internal.h"
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -615,6 +617,16 @@ __global__ __launch_bounds__(512, 2) void lv_bwd_dq_kernel(BwdParams p) {
     }
 }
 
+// dQ kernel choice: the ping-pong kernel (attn_bwd_dq_pp.hip) unless the environment variable
+// LVATTN_DQ_KERNEL=lockstep asks for the one in this file.
+static bool dq_pingpong() {
+    static bool v = [] {
+        const char* e = getenv("LVATTN_DQ_KERNEL");
+        return !(e && !strcmp(e, "lockstep"));
+    }();
+    return v;
+}
+
 template <int D>
 static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 block(512);
@@ -630,7 +642,9 @@ static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stre
             else hipLaunchKernelGGL((lv_bwd_dkdv_kernel<D, false, false>), grid, block, lds, stream, p);
         }
     }
-    if (p.n_qblocks > 0) {
+    if (p.n_qblocks > 0 && dq_pingpong()) {
+        lv_launch_bwd_dq_pp(p, D, causal, accum, stream);
+    } else if (p.n_qblocks > 0) {
         dim3 grid((unsigned)((int64_t)p.n_qblocks * p.hq));
         size_t lds = (size_t)4 * 64 * D * 2;
         if (causal) {
