@@ -8,8 +8,8 @@
 // The matrix phase is the longer one, so a SIMD's matrix pipe goes from one wave's matrix phase straight
 // into its partner's.  dQ = scale * dQ^T is written once; nothing is summed across workgroups.
 //
-// K/V tiles live in a 4-slot LDS ring (slot t%4 = [K tile t][V tile t]; MFMA(t+1) reads K and V of slot
-// t+1 by rows and K of slot t by columns).  Group A requests K tile t+2 and group B V tile t+3 in VALU(t)
+// K/V tiles live in a 5-slot LDS ring (slot t%5 = [K tile t][V tile t]; MFMA(t+1) reads K and V of slot
+// t+1 by rows and K of slot t by columns).  Group A requests K tile t+3 and group B V tile t+3 in VALU(t)
 // by direct global -> LDS loads; a counted s_waitcnt vmcnt before the phase-ending barrier leaves the
 // newest request in flight.
 #include "internal.h"
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
     constexpr int ROWB = D * 2;
     constexpr int TILEB = BN * ROWB;  // bytes per K or V tile
     constexpr int CPR = D / 8;
-    constexpr int NS = 4;             // ring slots
+    constexpr int NS = 5;             // ring slots
     constexpr int SLOTB = 2 * TILEB;  // [K tile][V tile]
     constexpr int RPP = 64 / CPR;     // rows per 1-KiB staging piece
     constexpr int PPW = (TILEB / 1024) / 4;  // pieces per wave per tile: 2 (d=128) or 1 (d=64)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
         // prologue: K tiles 0,1 (group A) / V tiles 0,1,2 (group B), then S_0 and dP_0 (both groups at once)
         issue_tile();
         issue_tile();
-        if (grp_b) issue_tile();
+        issue_tile();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -217,19 +217,21 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { dsf[0][i] = (__bf16)0.f; dsf[1][i] = (__bf16)0.f; }
             }
-            issue_tile();  // K tile t+2 (group A) or V tile t+3 (group B)
+            issue_tile();  // K (group A) or V (group B) tile t+3
+            // The vector phase is the short one: it also reads the first fragment group of the coming
+            // matrix phase, whose tiles were complete and visible at the barrier before this phase, so
+            // that the first MFMA after the barrier does not wait for LDS.
+            const int sb_old = sb;
+            sb = (sb + SLOTB == NS * SLOTB) ? 0 : sb + SLOTB;
+            load_group(0, 0, sb, sb_old);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW) : "memory");
             __builtin_amdgcn_sched_barrier(0);
 
             // ================= MFMA(t+1): S_{t+1}, dP_{t+1}, dQ += K_t^T dS_t =================
             __builtin_amdgcn_s_setprio(LV_PP_PRIO);
-            const int sb_old = sb;
-            sb = (sb + SLOTB == NS * SLOTB) ? 0 : sb + SLOTB;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-            load_group(0, 0, sb, sb_old);
-            __builtin_amdgcn_sched_group_barrier(0x100, RPG, 0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int set = g & 1;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 template <int D>
 static void launch_dq_pp(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 grid((unsigned)((int64_t)p.n_qblocks * p.hq)), block(512);
-    size_t lds = (size_t)4 * 2 * 32 * D * 2;  // 4 slots x (K tile + V tile) of 32 keys
+    size_t lds = (size_t)5 * 2 * 32 * D * 2;  // 5 slots x (K tile + V tile) of 32 keys
     if (causal) {
         if (accum) hipLaunchKernelGGL((lv_bwd_dq_pp_kernel<D, true, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((lv_bwd_dq_pp_kernel<D, true, false>), grid, block, lds, stream, p);
