@@ -9,8 +9,8 @@
 // into its partner's.  dQ = scale * dQ^T is written once; nothing is summed across workgroups.
 //
 // K/V tiles live in a 5-slot LDS ring (slot t%5 = [K tile t][V tile t]; MFMA(t+1) reads K and V of slot
-// t+1 by rows and K of slot t by columns).  Group A requests K tile t+3 and group B V tile t+3 in VALU(t)
-// by direct global -> LDS loads; a counted s_waitcnt vmcnt before the phase-ending barrier leaves the
+// t+1 by rows and K of slot t by columns).  Group A requests K tile t+4 and group B V tile t+4 late in
+// MFMA(t+1) by direct global -> LDS loads; a counted s_waitcnt vmcnt before the phase-ending barrier leaves the
 // newest request in flight.
 #include "internal.h"
 #include <type_traits>
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
     }
     float lse2 = p.lse[(int64_t)head * p.lse_stride + q_row];
     lse2 = (lse2 == -INFINITY) ? INFINITY : lse2 * 1.4426950408889634f;  // rows without keys: P = 0
-    const float delta = p.delta[(int64_t)head * p.lse_stride + q_row];
+    float delta = p.delta[(int64_t)head * p.lse_stride + q_row];
 
     int limit = qi + shift;
     if (limit > k_len - 1 || qi >= q_rows) limit = k_len - 1;
@@ -156,8 +156,11 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dsf[0][i] = (__bf16)0.f; dsf[1][i] = (__bf16)0.f; }
 
+    // Retire every ordinary global load here.  The compiler does not see the staging loads, so a wait
+    // it placed at the first use inside the loop would be vmcnt(0) and drain them on every tile.
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(qf[ks])); asm volatile("" : "+v"(dof[ks])); }
+    asm volatile("" : "+v"(lse2), "+v"(delta));
 
     // fragments of one MFMA group: SPG K rows, SPG V rows (slot sb_new), QPG K columns (slot sb_old)
     bf16x8 kfr[2][SPG], vfr[2][SPG], tfr[2][QPG];
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
     };
 
     if (nkt > 0) {
-        // prologue: K tiles 0,1 (group A) / V tiles 0,1,2 (group B), then S_0 and dP_0 (both groups at once)
+        // prologue: tiles 0..3 of this group's operand, then S_0 and dP_0 (both groups at once)
+        issue_tile();
         issue_tile();
         issue_tile();
         issue_tile();
@@ -200,9 +204,15 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
             if (t < my_nkt) {
                 const int kb0 = t * BN;
                 const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len);
+                // all the multiply-adds, then all the exponentials, then their consumers: back to back a
+                // dependent pair would stall on the first one's latency sixteen times over
                 float pv[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(__builtin_fmaf(s[i], c, -lse2));
+                for (int i = 0; i < 16; ++i) pv[i] = __builtin_fmaf(s[i], c, -lse2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(pv[i]);
+                __builtin_amdgcn_sched_barrier(0);
                 if (need_mask) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -217,10 +227,9 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { dsf[0][i] = (__bf16)0.f; dsf[1][i] = (__bf16)0.f; }
             }
-            issue_tile();  // K (group A) or V (group B) tile t+3
-            // The vector phase is the short one: it also reads the first fragment group of the coming
-            // matrix phase, whose tiles were complete and visible at the barrier before this phase, so
-            // that the first MFMA after the barrier does not wait for LDS.
+            // The vector phase also reads the first fragment group of the coming matrix phase, whose tiles
+            // were complete and visible at the barrier before this phase, so that the first MFMA after
+            // the barrier does not wait for LDS.
             const int sb_old = sb;
             sb = (sb + SLOTB == NS * SLOTB) ? 0 : sb + SLOTB;
             load_group(0, 0, sb, sb_old);
@@ -260,6 +269,13 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
                     }
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+                }
+                if (g == NG - 2) {
+                    // the staging request (K tile t+4 for group A, V tile t+4 for group B) rides late in the
+                    // matrix phase: all its LDS reads are out, and its scalar work fits between the MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_tile();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
