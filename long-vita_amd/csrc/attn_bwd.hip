@@ -627,10 +627,22 @@ static bool dq_pingpong() {
     return v;
 }
 
+// dK/dV kernel choice: the role-split kernel (attn_bwd_dkdv_rs.hip) unless the environment variable
+// LVATTN_DKDV_KERNEL=single asks for the one-wave-per-SIMD kernel in this file.
+static bool dkdv_role_split() {
+    static bool v = [] {
+        const char* e = getenv("LVATTN_DKDV_KERNEL");
+        return !(e && !strcmp(e, "single"));
+    }();
+    return v;
+}
+
 template <int D>
 static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 block(512);
-    if (p.n_blocks > 0) {
+    if (p.n_blocks > 0 && dkdv_role_split()) {
+        lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);
+    } else if (p.n_blocks > 0) {
         dim3 grid((unsigned)((int64_t)p.n_blocks * p.hkv));
         dim3 block(256);
         size_t lds = (size_t)LV_BWD_RING * (2 * 32 * D * 2 + 4 * 256);  // ring slots of (Q slice, dO slice, row constants)

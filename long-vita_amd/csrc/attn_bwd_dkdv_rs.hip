@@ -1,0 +1,319 @@
+// dK / dV kernel of the attention backward for gfx950, "role-split" form.
+//
+// One workgroup = 8 waves = one 128-key block of one K/V head.  The two waves of a SIMD own the SAME
+// 32 keys (key on the lane) and split the work on them:
+//   V-wave (waves 0-3): S = Q K^T, P = exp2(c S - lse2) (masked, bf16), hands P to its partner through
+//                       LDS, dV^T += dO^T P                    -> K fragments + dV^T accumulators in registers
+//   K-wave (waves 4-7): dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS
+//                                                              -> V fragments + dK^T accumulators in registers
+// 16 MFMAs per 32-row query slice each.  The K-wave runs one slice behind the V-wave (it needs P), so
+// one workgroup barrier per slice is enough, and on every SIMD one wave's vector work (exp / dS) sits
+// beside the other's matrix work.  With the accumulators split, a wave needs < 256 registers, which is
+// what lets two of them share a SIMD; no gradient is summed across workgroups.
+//
+// Q / dO / lse / delta of a slice arrive by direct global -> LDS loads into a 5-slot ring (slices
+// it-1 .. it+3 around the V-wave's slice `it`), each wave fetching 1/8 of a slice plus its own copy of
+// the row constants; a counted s_waitcnt vmcnt before the barrier leaves the newest request in flight.
+// The sweep walks the query slices from the last one down (see attn_bwd.hip).
+#include "internal.h"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+template <int D>
+__device__ __forceinline__ int lds_off_rs(int row, int chunk) {
+    if constexpr (D == 128) return lds_off128(row, chunk);
+    else return lds_off64(row, chunk);
+}
+
+// Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i or + 4 i; lds_dst in M0).  As asm so
+// that the compiler does not count them; completion is waited for by hand.
+__device__ __forceinline__ void rs_dma16(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void rs_dma4(const float* g, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
+template <int D, bool CAUSAL, bool ACCUM_F32>
+__global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
+    constexpr int NW = 8;
+    constexpr int BQ = 32;             // query rows per slice
+    constexpr int KS = D / 16;
+    constexpr int MT = D / 32;
+    constexpr int ROWB = D * 2;
+    constexpr int CPR = D / 8;
+    constexpr int QTILE = BQ * ROWB;   // bytes of a Q (or dO) slice
+    constexpr int NBUF = 5;            // ring slots
+    constexpr int AHEAD = 3;           // staging distance in slices
+    constexpr int SLOTB = 2 * QTILE + NW * 256;  // [Q slice][dO slice][8 x (32 lse, 32 delta) f32: one copy per wave]
+    constexpr int RPP = 64 / CPR;                 // rows per 1-KiB piece
+    constexpr int PPW = (2 * QTILE / 1024) / NW;  // pieces per wave per slice: 2 (d=128) or 1 (d=64)
+    constexpr int LPI = PPW + 1;                  // loads per wave per slice
+    constexpr int PBUF = 4 * 2048;                // P of one slice: 4 wave pairs x (64 lanes x 32 bytes)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char* const lds0 = (lds_char*)smem;
+    lds_char* const ldsP = lds0 + NBUF * SLOTB;   // [2][PBUF]
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_k = (w >= 4);        // K-wave (dK) or V-wave (dV)
+    const int pair = w & 3;            // which 32 keys
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int blk = bid % p.n_blocks;
+    const int kvh = bid / p.n_blocks;
+
+    const AttnDesc dsc = p.desc[blk];
+    const int k_row0 = dsc.a_row0, k_rows = dsc.a_rows;
+    const int q_row0 = dsc.b_row0, q_len = dsc.b_len;
+    const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
+    const int nslice = (q_len + BQ - 1) / BQ;
+    const int niter = nslice * p.group;
+
+    // ---- this wave's B operand: K fragments (V-wave) or V fragments (K-wave) of key 32*pair + r
+    const int kbase_w = 32 * pair;
+    const int kj = kbase_w + r;
+    bf16x8 bfr[KS];
+    {
+        const int grow = k_row0 + (kj < k_rows ? kj : k_rows - 1);
+        const __bf16* bp = is_k ? p.v + (int64_t)grow * p.v_rs + (int64_t)kvh * p.v_hs + 8 * h
+                                : p.k + (int64_t)grow * p.k_rs + (int64_t)kvh * p.k_hs + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(bp + 16 * ks);
+    }
+    // retire these loads now: inside the loop the only memory counter traffic is the staging
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bfr[ks]));
+
+    // ---- staging of a (slice, head): waves 0-3 bring the Q rows, waves 4-7 the dO rows; piece j of
+    // wave w is rows RPP*(PPW*(w&3) + j) .. +RPP-1.  The swizzle of the LDS image goes on the source.
+    const int64_t x_rs = is_k ? p.do_rs : p.q_rs;
+    const int64_t x_hs = is_k ? p.do_hs : p.q_hs;
+    const __bf16* const x_base = (is_k ? p.dout : p.q) + (int64_t)q_row0 * x_rs;
+    const int prow0 = RPP * PPW * pair + lane / CPR;
+    const int rows_last = q_len - (nslice - 1) * BQ;  // only the last slice (the first one requested) can be partial
+    int voff_full[PPW], voff_part[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = prow0 + RPP * j;
+        const int ch16 = lds_off_rs<D>(row, lane % CPR) - row * ROWB;
+        voff_full[j] = row * (int)(x_rs * 2) + ch16;
+        voff_part[j] = min(row, rows_last - 1) * (int)(x_rs * 2) + ch16;  // rows past the end repeat the last valid one
+    }
+    const int c_part = min(r, rows_last - 1) - r;
+    int ld_sl = nslice - 1, ld_hg = 0, ld_n = 0;  // (slice, head) of the next request; requests so far
+    uint32_t ld_slot = lds_base;
+    const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
+    const int64_t x_step_head = x_hs * 2;
+    const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
+    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31
+    const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
+    const int64_t c_step_head = p.lse_stride;
+    const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+        const bool partial = (ld_sl == nslice - 1);
+        const int rows_valid = partial ? rows_last : BQ;
+        auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ld_x), 0, (uint32_t)((rows_valid - 1) * x_rs * 2 + ROWB), 0x00020000);
+        const uint32_t dst = ld_slot + (is_k ? QTILE : 0) + PPW * pair * 1024;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) rs_dma16(rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
+        rs_dma4(ld_c + (partial ? c_part : 0), ld_slot + 2 * QTILE + w * 256);  // every wave keeps its own copy
+        // past the last slice the stream stays where it is: the loop's unconditional requests re-fetch
+        // that slice into a slot nobody reads any more
+        const bool adv = (++ld_n < niter);
+        const bool wrap = (ld_hg + 1 == p.group);
+        const int64_t xs = wrap ? x_step_slice : x_step_head, cs = wrap ? c_step_slice : c_step_head;
+        ld_x += adv ? xs : 0;
+        ld_c += adv ? cs : 0;
+        ld_hg = adv ? (wrap ? 0 : ld_hg + 1) : ld_hg;
+        ld_sl = (adv && wrap) ? ld_sl - 1 : ld_sl;
+        ld_slot = (ld_slot + SLOTB == lds_base + NBUF * SLOTB) ? lds_base : ld_slot + SLOTB;
+    };
+
+    // ---- LDS read addresses in slot 0.  The V-wave reads Q by rows and dO by columns, the K-wave dO by
+    // rows and Q by columns: one pointer set each, pre-offset to the wave's two operands.
+    const int row_op = is_k ? QTILE : 0;   // operand read by rows
+    const int col_op = is_k ? 0 : QTILE;   // operand read by columns
+    lds_char* a_ptr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_ptr[ks] = lds0 + row_op + lds_off_rs<D>(r, 2 * ks + h);
+    const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gl = (lane >> 4) & 1;
+    lds_char* t_ptr[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+            t_ptr[mt][jh] = lds0 + col_op + lds_off_rs<D>(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
+    // this wave's copy of the row constants: lse2 (V-wave) or delta (K-wave) of rows 8g+4h .. +3
+    lds_char* const ld_ptr = lds0 + 2 * QTILE + w * 256 + 16 * h + (is_k ? 128 : 0);
+    lds_char* const ld_lane_ptr = lds0 + 2 * QTILE + w * 256 + 4 * lane;   // one float per lane, for the rescaling pass
+    const float ld_lane_mul = (lane < 32) ? 1.4426950408889634f : 1.f;
+    lds_char* const p_ptr = ldsP + pair * 2048 + lane * 32;                // this lane's P (two 16-byte halves)
+
+    f32x16 acc[MT];   // dV^T (V-wave) or dK^T (K-wave)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    const float c = p.scale_log2e;
+
+    // the staged lse is in natural-log units; the V-wave rewrites its copy as lse * log2(e), one float per lane
+    auto rescale_lse = [&](int sb) __attribute__((always_inline)) {
+        float v = *(LDS_PTR(float, ld_lane_ptr + sb));
+        *(LDS_PTR(float, ld_lane_ptr + sb)) = v * ld_lane_mul;
+    };
+    auto wait_and_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 2) * LPI) : "memory");
+    };
+
+    if (niter > 0) {
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) issue_dma();
+        wait_and_barrier();   // slices 0 and 1 landed
+        if (!is_k) rescale_lse(0);
+    }
+
+    int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of the V-wave's slice
+    int sb = 0, sb_prev = 0;          // ring byte offsets of the V-wave's slice and of the one before it
+    // Both roles run the SAME straight-line body, with role-dependent operand addresses:
+    //   X = A_rows B^T   (V-wave: S = Q K^T      K-wave: dP = dO V^T)       8 MFMAs
+    //   Y = f(X)         (V-wave: P              K-wave: dS = P (dP - delta))  a short branch on X, Y only
+    //   acc += A_cols^T Y (V-wave: dV^T += dO^T P  K-wave: dK^T += Q^T dS)    8 MFMAs
+    // so that the accumulators never cross a control-flow merge (the compiler would copy all 64 of
+    // them there).  An iteration without work for a role (K-wave in the first, V-wave in the last)
+    // runs on a landed slot with Y = 0.
+    for (int it = 0; it <= niter; ++it) {
+        const int i0 = c_sl * BQ;  // first query row of the V-wave's slice, relative to q_row0
+        if (++c_hg == p.group) { c_hg = 0; --c_sl; }
+        const int sb_next = (sb + SLOTB == NBUF * SLOTB) ? 0 : sb + SLOTB;
+        issue_dma();   // slice it+3; its slot held slice it-2, which both roles finished with before the last barrier
+        const int my_sb = is_k ? sb_prev : sb;
+        const bool valid = is_k ? (it > 0) : (it < niter);
+
+        f32x16 x;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks] + my_sb));
+            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x, 0, 0, 0);
+        }
+        bf16x8 y[2];
+        if (!is_k) {
+            // ---- V-wave: P = exp2(c S - lse2), masked; handed to the partner through LDS
+            rescale_lse(sb_next);  // for the next iteration (slice it+1 landed before the last barrier)
+            const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+            float pv[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 l4 = *(LDS_PTR(f32x4, ld_ptr + my_sb + 32 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(__builtin_fmaf(x[4 * g + e], c, -l4[e]));
+            }
+            if (need_mask || !valid) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows) | !valid;
+                    pv[i] = dead ? 0.f : pv[i];
+                    asm volatile("" : "+v"(pv[i]));  // keeps this a branch
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y[i >> 3][i & 7] = (__bf16)pv[i];
+            *(LDS_PTR(bf16x8, p_ptr + (it & 1) * PBUF)) = y[0];
+            *(LDS_PTR(bf16x8, p_ptr + (it & 1) * PBUF + 16)) = y[1];
+        } else {
+            // ---- K-wave: dS = P (dP - delta) for the slice the partner finished last iteration
+            bf16x8 pf[2];
+            pf[0] = *(LDS_PTR(bf16x8, p_ptr + ((it + 1) & 1) * PBUF));
+            pf[1] = *(LDS_PTR(bf16x8, p_ptr + ((it + 1) & 1) * PBUF + 16));
+            const float keep = valid ? 1.f : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 d4 = *(LDS_PTR(f32x4, ld_ptr + my_sb + 32 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e;
+                    const float pb = (float)pf[i >> 3][i & 7] * keep;  // (bf16 -> f32 is exact)
+                    y[i >> 3][i & 7] = (__bf16)(pb * (x[i] - d4[e]));
+                }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][0] + my_sb + 16 * s2 * ROWB));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][1] + my_sb + 16 * s2 * ROWB));
+                bf16x8 af;
+                af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+                af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, y[s2], acc[mt], 0, 0, 0);
+            }
+        sb_prev = sb;
+        sb = sb_next;
+        // slice it+2 must have landed before the next iteration rescales its lse; the request issued
+        // after it stays in flight across the barrier
+        wait_and_barrier();
+    }
+    // no staging request may outlive the workgroup: its LDS could already belong to another one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: accumulators (key on the lane) -> rows of dv (V-wave) or dk (K-wave, times scale)
+    if (kj < k_rows) {
+        const int64_t grow = k_row0 + kj;
+        const float f = is_k ? p.scale : 1.f;
+        void* const gbase = is_k ? p.dk : p.dv;
+        const int64_t g_rs = is_k ? p.dk_rs : p.dv_rs, g_hs = is_k ? p.dk_hs : p.dv_hs;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dcol = 32 * mt + 8 * g4 + 4 * h;
+                if constexpr (ACCUM_F32) {
+                    float* gp = reinterpret_cast<float*>(gbase) + grow * g_rs + (int64_t)kvh * g_hs + dcol;
+                    f32x4 a = *reinterpret_cast<f32x4*>(gp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] += acc[mt][4 * g4 + e] * f;
+                    *reinterpret_cast<f32x4*>(gp) = a;
+                } else {
+                    __bf16* gp = reinterpret_cast<__bf16*>(gbase) + grow * g_rs + (int64_t)kvh * g_hs + dcol;
+                    bf16x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = (__bf16)(acc[mt][4 * g4 + e] * f);
+                    *reinterpret_cast<bf16x4*>(gp) = a;
+                }
+            }
+    }
+}
+
+template <int D>
+static void launch_rs(const BwdParams& p, int causal, int accum, hipStream_t stream) {
+    dim3 grid((unsigned)((int64_t)p.n_blocks * p.hkv)), block(512);
+    size_t lds = (size_t)5 * (2 * 32 * D * 2 + 8 * 256) + 2 * 4 * 2048;  // ring slots + two P buffers
+    if (causal) {
+        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, false>), grid, block, lds, stream, p);
+    } else {
+        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, false, false>), grid, block, lds, stream, p);
+    }
+}
+
+int lv_launch_bwd_dkdv_rs(const BwdParams& p, int d, int causal, int accum, hipStream_t stream) {
+    if (p.n_blocks <= 0) return 0;
+    if (d == 128) launch_rs<128>(p, causal, accum, stream);
+    else launch_rs<64>(p, causal, accum, stream);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

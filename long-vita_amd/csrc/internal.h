@@ -37,6 +37,7 @@ struct BwdParams {
     float scale, scale_log2e;
 };
 int lv_launch_bwd(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);
+int lv_launch_bwd_dkdv_rs(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);  // role-split dK/dV kernel
 int lv_launch_bwd_dq_pp(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);  // ping-pong dQ kernel
 int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows, int hq, int d, int64_t o_rs, int64_t o_hs,
                         int64_t do_rs, int64_t do_hs, int64_t lse_stride, hipStream_t stream);
