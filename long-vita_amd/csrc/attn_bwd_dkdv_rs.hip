@@ -172,100 +172,138 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
         float v = *(LDS_PTR(float, ld_lane_ptr + sb));
         *(LDS_PTR(float, ld_lane_ptr + sb)) = v * ld_lane_mul;
     };
-    auto wait_and_barrier = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 2) * LPI) : "memory");
+
+    // Both roles run the SAME loop, with role-dependent operand addresses, the K-waves one barrier
+    // behind the V-waves:
+    //   VALU(s) : Y_s = f(X_s)     V-wave: P_s = exp2(c S_s - lse2), masked, also written to LDS for the partner
+    //                              K-wave: dS_s = P_s (dP_s - delta), P_s read back from LDS
+    //   MFMA(s) : X_{s+1} = A_rows(slice s+1) B^T   (V: S = Q K^T        K: dP = dO V^T)        8 MFMAs
+    //             acc    += A_cols(slice s)^T Y_s    (V: dV^T += dO^T P   K: dK^T += Q^T dS)     8 MFMAs
+    // so on every SIMD one wave is in its matrix phase while its partner is in its vector phase, and the
+    // accumulators never cross a control-flow merge.  The LDS fragments of MFMA group g+1 are read while
+    // group g runs.
+    constexpr int NG = 4;               // MFMA groups per matrix phase
+    constexpr int XPG = KS / NG;        // X-chain steps per group: 2 or 1
+    constexpr int APG = (2 * MT) / NG;  // accumulator products per group: 2 or 1
+    bf16x8 rfr[2][XPG], cfr[2][APG];
+    auto load_group = [&](int g, int set, int sb_x, int sb_a) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XPG; ++i) rfr[set][i] = *(LDS_PTR(bf16x8, a_ptr[XPG * g + i] + sb_x));
+#pragma unroll
+        for (int i = 0; i < APG; ++i) {
+            const int j = APG * g + i, s2 = j / MT, mt = j % MT;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][0] + sb_a + 16 * s2 * ROWB));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][1] + sb_a + 16 * s2 * ROWB));
+            bf16x8& af = cfr[set][i];
+            af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+            af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+        }
     };
 
     if (niter > 0) {
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) issue_dma();
-        wait_and_barrier();   // slices 0 and 1 landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (!is_k) rescale_lse(0);
-    }
-
-    int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of the V-wave's slice
-    int sb = 0, sb_prev = 0;          // ring byte offsets of the V-wave's slice and of the one before it
-    // Both roles run the SAME straight-line body, with role-dependent operand addresses:
-    //   X = A_rows B^T   (V-wave: S = Q K^T      K-wave: dP = dO V^T)       8 MFMAs
-    //   Y = f(X)         (V-wave: P              K-wave: dS = P (dP - delta))  a short branch on X, Y only
-    //   acc += A_cols^T Y (V-wave: dV^T += dO^T P  K-wave: dK^T += Q^T dS)    8 MFMAs
-    // so that the accumulators never cross a control-flow merge (the compiler would copy all 64 of
-    // them there).  An iteration without work for a role (K-wave in the first, V-wave in the last)
-    // runs on a landed slot with Y = 0.
-    for (int it = 0; it <= niter; ++it) {
-        const int i0 = c_sl * BQ;  // first query row of the V-wave's slice, relative to q_row0
-        if (++c_hg == p.group) { c_hg = 0; --c_sl; }
-        const int sb_next = (sb + SLOTB == NBUF * SLOTB) ? 0 : sb + SLOTB;
-        issue_dma();   // slice it+3; its slot held slice it-2, which both roles finished with before the last barrier
-        const int my_sb = is_k ? sb_prev : sb;
-        const bool valid = is_k ? (it > 0) : (it < niter);
-
         f32x16 x;
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks] + my_sb));
+            bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks]));
             x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x, 0, 0, 0);
         }
         bf16x8 y[2];
-        if (!is_k) {
-            // ---- V-wave: P = exp2(c S - lse2), masked; handed to the partner through LDS
-            rescale_lse(sb_next);  // for the next iteration (slice it+1 landed before the last barrier)
-            const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
-            float pv[16];
+        int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of slice s
+        int sb = 0;                       // ring byte offset of slice s
+        if (is_k) asm volatile("s_barrier" ::: "memory");
+        for (int s = 0; s < niter; ++s) {
+            const int i0 = c_sl * BQ;  // first query row of slice s, relative to q_row0
+            if (++c_hg == p.group) { c_hg = 0; --c_sl; }
+            const int sb_next = (sb + SLOTB == NBUF * SLOTB) ? 0 : sb + SLOTB;
+            // ================= VALU(s) =================
+            if (!is_k) {
+                rescale_lse(sb_next);  // slice s+1 landed before the last barrier of this wave's vector phase
+                const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+                float pv[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 l4 = *(LDS_PTR(f32x4, ld_ptr + my_sb + 32 * g));
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 l4 = *(LDS_PTR(f32x4, ld_ptr + sb + 32 * g));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(__builtin_fmaf(x[4 * g + e], c, -l4[e]));
-            }
-            if (need_mask || !valid) {
+                    for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(__builtin_fmaf(x[4 * g + e], c, -l4[e]));
+                }
+                if (need_mask) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows) | !valid;
-                    pv[i] = dead ? 0.f : pv[i];
-                    asm volatile("" : "+v"(pv[i]));  // keeps this a branch
+                    for (int i = 0; i < 16; ++i) {
+                        int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
+                        pv[i] = dead ? 0.f : pv[i];
+                        asm volatile("" : "+v"(pv[i]));  // keeps this a branch
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[i >> 3][i & 7] = (__bf16)pv[i];
+                *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF)) = y[0];
+                *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF + 16)) = y[1];
+            } else {
+                bf16x8 pf[2];
+                pf[0] = *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF));
+                pf[1] = *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF + 16));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 d4 = *(LDS_PTR(f32x4, ld_ptr + sb + 32 * g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g + e;
+                        y[i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * (x[i] - d4[e]));  // (bf16 -> f32 is exact)
+                    }
                 }
             }
+            asm volatile("" : "+v"(y[0]), "+v"(y[1]));  // Y is formed here, not next to its first use
+            issue_dma();   // slice s+3; its slot held slice s-2, whose last reader finished two barriers ago
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPI) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ================= MFMA(s): X_{s+1} and acc += A_cols(s)^T Y_s =================
+            __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y[i >> 3][i & 7] = (__bf16)pv[i];
-            *(LDS_PTR(bf16x8, p_ptr + (it & 1) * PBUF)) = y[0];
-            *(LDS_PTR(bf16x8, p_ptr + (it & 1) * PBUF + 16)) = y[1];
-        } else {
-            // ---- K-wave: dS = P (dP - delta) for the slice the partner finished last iteration
-            bf16x8 pf[2];
-            pf[0] = *(LDS_PTR(bf16x8, p_ptr + ((it + 1) & 1) * PBUF));
-            pf[1] = *(LDS_PTR(bf16x8, p_ptr + ((it + 1) & 1) * PBUF + 16));
-            const float keep = valid ? 1.f : 0.f;
+            for (int i = 0; i < 16; ++i) x[i] = 0.f;
+            load_group(0, 0, sb_next, sb);
+            __builtin_amdgcn_sched_group_barrier(0x100, XPG + 2 * APG, 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 d4 = *(LDS_PTR(f32x4, ld_ptr + my_sb + 32 * g));
+            for (int g = 0; g < NG; ++g) {
+                const int set = g & 1;
+                if (g + 1 < NG) load_group(g + 1, set ^ 1, sb_next, sb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * g + e;
-                    const float pb = (float)pf[i >> 3][i & 7] * keep;  // (bf16 -> f32 is exact)
-                    y[i >> 3][i & 7] = (__bf16)(pb * (x[i] - d4[e]));
+                for (int i = 0; i < XPG; ++i) {
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfr[set][i], bfr[XPG * g + i], x, 0, 0, 0);
+                    if (i < APG) {
+                        const int j = APG * g + i;
+                        acc[j % MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfr[set][i], y[j / MT], acc[j % MT], 0, 0, 0);
+                    }
+                }
+                static_assert(APG == XPG, "one accumulator product per X-chain step");
+                if (g + 1 < NG) {
+                    // issue order: the next group's reads (3 per 2 MFMAs) between this group's MFMAs
+#pragma unroll
+                    for (int i = 0; i < XPG; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * XPG, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            sb = sb_next;
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][0] + my_sb + 16 * s2 * ROWB));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[mt][1] + my_sb + 16 * s2 * ROWB));
-                bf16x8 af;
-                af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
-                af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, y[s2], acc[mt], 0, 0, 0);
-            }
-        sb_prev = sb;
-        sb = sb_next;
-        // slice it+2 must have landed before the next iteration rescales its lse; the request issued
-        // after it stays in flight across the barrier
-        wait_and_barrier();
+        if (!is_k) asm volatile("s_barrier" ::: "memory");
     }
     // no staging request may outlive the workgroup: its LDS could already belong to another one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
