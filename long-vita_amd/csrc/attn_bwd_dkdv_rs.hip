@@ -154,10 +154,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh)
             t_ptr[mt][jh] = lds0 + col_op + lds_off_rs<D>(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
-    // this wave's copy of the row constants: lse2 (V-wave) or delta (K-wave) of rows 8g+4h .. +3
+    // this wave's copy of the row constants: lse (V-wave) or delta (K-wave) of rows 8g+4h .. +3
     lds_char* const ld_ptr = lds0 + 2 * QTILE + w * 256 + 16 * h + (is_k ? 128 : 0);
-    lds_char* const ld_lane_ptr = lds0 + 2 * QTILE + w * 256 + 4 * lane;   // one float per lane, for the rescaling pass
-    const float ld_lane_mul = (lane < 32) ? 1.4426950408889634f : 1.f;
     lds_char* const p_ptr = ldsP + pair * 2048 + lane * 32;                // this lane's P (two 16-byte halves)
 
     f32x16 acc[MT];   // dV^T (V-wave) or dK^T (K-wave)
@@ -166,12 +164,6 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
     const float c = p.scale_log2e;
-
-    // the staged lse is in natural-log units; the V-wave rewrites its copy as lse * log2(e), one float per lane
-    auto rescale_lse = [&](int sb) __attribute__((always_inline)) {
-        float v = *(LDS_PTR(float, ld_lane_ptr + sb));
-        *(LDS_PTR(float, ld_lane_ptr + sb)) = v * ld_lane_mul;
-    };
 
     // Both roles run the SAME loop, with role-dependent operand addresses, the K-waves one barrier
     // behind the V-waves:
@@ -204,7 +196,6 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) issue_dma();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (!is_k) rescale_lse(0);
         f32x16 x;
 #pragma unroll
         for (int i = 0; i < 16; ++i) x[i] = 0.f;
@@ -213,6 +204,19 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
             bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks]));
             x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x, 0, 0, 0);
         }
+        // row constants of slice s, read one matrix phase ahead: -lse * log2(e) (V-wave) or -delta (K-wave)
+        // of rows 8g+4h .. +3, so that the vector phase starts on registers, not on an LDS round trip
+        const float cmul = is_k ? -1.f : -1.4426950408889634f;
+        f32x4 cst[4];
+        auto load_consts = [&](int sbx) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t4 = *(LDS_PTR(f32x4, ld_ptr + sbx + 32 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cst[g][e] = t4[e] * cmul;
+            }
+        };
+        load_consts(0);
         bf16x8 y[2];
         int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of slice s
         int sb = 0;                       // ring byte offset of slice s
@@ -223,15 +227,10 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
             const int sb_next = (sb + SLOTB == NBUF * SLOTB) ? 0 : sb + SLOTB;
             // ================= VALU(s) =================
             if (!is_k) {
-                rescale_lse(sb_next);  // slice s+1 landed before the last barrier of this wave's vector phase
                 const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
                 float pv[16];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 l4 = *(LDS_PTR(f32x4, ld_ptr + sb + 32 * g));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pv[4 * g + e] = fast_exp2(__builtin_fmaf(x[4 * g + e], c, -l4[e]));
-                }
+                for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(__builtin_fmaf(x[i], c, cst[i >> 2][i & 3]));
                 if (need_mask) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -250,14 +249,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                 pf[0] = *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF));
                 pf[1] = *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF + 16));
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 d4 = *(LDS_PTR(f32x4, ld_ptr + sb + 32 * g));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * g + e;
-                        y[i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * (x[i] - d4[e]));  // (bf16 -> f32 is exact)
-                    }
-                }
+                for (int i = 0; i < 16; ++i)
+                    y[i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * (x[i] + cst[i >> 2][i & 3]));  // (bf16 -> f32 is exact)
             }
             asm volatile("" : "+v"(y[0]), "+v"(y[1]));  // Y is formed here, not next to its first use
             issue_dma();   // slice s+3; its slot held slice s-2, whose last reader finished two barriers ago
@@ -297,6 +290,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * XPG, 0);
                 }
             }
+            load_consts(sb_next);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
