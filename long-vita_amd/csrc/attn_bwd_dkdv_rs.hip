@@ -20,6 +20,13 @@
 
 typedef __attribute__((address_space(3))) char lds_char;
 
+#ifndef LV_RS_PRIO_M
+#define LV_RS_PRIO_M 2   // s_setprio level in the matrix phase
+#endif
+#ifndef LV_RS_PRIO_V
+#define LV_RS_PRIO_V 0   // s_setprio level in the vector phase
+#endif
+
 template <int D>
 __device__ __forceinline__ int lds_off_rs(int row, int chunk) {
     if constexpr (D == 128) return lds_off128(row, chunk);
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
             __builtin_amdgcn_sched_barrier(0);
 
             // ================= MFMA(s): X_{s+1} and acc += A_cols(s)^T Y_s =================
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(LV_RS_PRIO_M);
 #pragma unroll
             for (int i = 0; i < 16; ++i) x[i] = 0.f;
             load_group(0, 0, sb_next, sb);
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
             }
             load_consts(sb_next);
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(LV_RS_PRIO_V);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             sb = sb_next;
