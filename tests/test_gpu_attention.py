@@ -109,6 +109,8 @@ BWD_CASES = [
     ("bwd_dense_d64", [0, 1025], 2, 2, 64, False),
     ("bwd_dense_d128", [0, 200, 520], 4, 2, 128, False),
     ("bwd_causal_d64", [0, 130, 450], 4, 2, 64, True),
+    ("bwd_tiny_segments", [0, 1, 3, 40, 41, 300], 4, 2, 128, True),
+    ("bwd_group5_long", [0, 2500], 5, 1, 128, True),
 ]
 
 
