@@ -15,8 +15,9 @@ compute stream.  Per step the work is one of three rectangles of the score matri
   KV from an earlier rank: all local queries x first KV chunk (2c x c, no mask)
   KV from a later rank   : second query chunk x whole KV block (c x 2c, no mask)
 each worth the same FLOPs, merged into a running (out fp32, log-sum-exp) pair.
-The backward pass sends the K/V block and its fp32 dK/dV accumulator round the
-same ring and returns the accumulator to its owner with one extra hop.
+The backward pass sends the K/V block and the fp32 running sum of its dK/dV round the
+same ring (each rank computes its contribution while the sum is still arriving, then adds
+and forwards) and returns the finished sum to the block's owner with one extra hop.
 
 The block arithmetic goes through a small backend object so that the schedule and
 the communication can be exercised on CPU (gloo) in tests with a checker backend;
@@ -194,28 +195,43 @@ class RingAttention:
         dout3 = dout.reshape(s_loc, b * n_heads, d)
         delta = be.delta(out3, dout3, lse)
         kv = [torch.stack([k.reshape(s_loc, b * hkv, d), v.reshape(s_loc, b * hkv, d)]), None]
-        dkv = [torch.zeros((2, s_loc, b * hkv, d), dtype=torch.float32, device=q.device), None]
+        # dK/dV of a K/V block is the sum of one contribution per rank; the running sum follows the
+        # block round the ring.  Each step computes the local contribution into `dloc` while the sum for
+        # this block is still arriving from the previous rank, then adds and forwards: the fp32
+        # accumulator traffic (twice the K/V bytes) overlaps the block kernels as the K/V traffic does.
+        dloc = torch.empty((2, s_loc, b * hkv, d), dtype=torch.float32, device=q.device)
+        dbuf = [None, None]
         if self.cp > 1:
             kv[1] = torch.empty_like(kv[0])
-            dkv[1] = torch.empty_like(dkv[0])
+            dbuf = [torch.empty_like(dloc), torch.empty_like(dloc)]
         dq_acc = torch.zeros((s_loc, b * n_heads, d), dtype=torch.float32, device=q.device)
         side = self._comm(q.device)
         nxt, prv = self._peers()
+        pending = None   # exchange of the running sum started at the end of the previous step
         for step in range(self.cp):
             cur, oth = kv[step % 2], kv[(step + 1) % 2]
-            dcur, doth = dkv[step % 2], dkv[(step + 1) % 2]
             handle = None
             if step + 1 < self.cp:
                 handle = side.exchange([cur], [oth], nxt, prv)   # K/V travels ahead of the math
             qr, kr, causal, shift = self.step_rect(step, s_loc)
-            be.block_bwd(q3, cur[0], cur[1], out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dcur[0], dcur[1])
+            dloc.zero_()
+            be.block_bwd(q3, cur[0], cur[1], out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dloc[0], dloc[1])
             if handle is not None:
                 side.wait(handle)
             if self.cp > 1:
-                # the accumulator follows its K/V block; after the last step one more hop returns it home
-                h2 = side.exchange([dcur], [doth], nxt, prv)
-                side.wait(h2)
-        final = dkv[self.cp % 2] if self.cp > 1 else dkv[0]
+                send = dbuf[(step + 1) % 2]
+                if pending is not None:
+                    side.wait(pending)      # `send` now holds the sum so far for this block, from the previous rank
+                    send.add_(dloc)
+                else:
+                    send.copy_(dloc)
+                # after the last step this hop returns the finished sum to the block's owner
+                pending = side.exchange([send], [dbuf[step % 2]], nxt, prv)
+        if self.cp > 1:
+            side.wait(pending)
+            final = dbuf[(self.cp - 1) % 2]
+        else:
+            final = dloc
         dq = be.cast(dq_acc, q.dtype).reshape(s_loc, b, hq_d)
         dk = be.cast(final[0], k.dtype).reshape(s_loc, b, hkv * d)
         dv = be.cast(final[1], v.dtype).reshape(s_loc, b, hkv * d)

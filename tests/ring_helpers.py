@@ -67,25 +67,42 @@ class CheckerBackend:
 
 
 class LoopbackFabric:
-    """Queues shared by the virtual ranks of one process."""
+    """Mailboxes shared by the virtual ranks of one process.  Like RCCL / gloo point-to-point traffic,
+    the n-th receive a rank POSTS from a peer matches the n-th send that peer posted to it, whatever
+    order the receives are waited for in."""
 
     def __init__(self, n):
-        self.q = {(s, d): queue.Queue() for s in range(n) for d in range(n)}
+        self.n = n
+        self.lock = threading.Lock()
+        self.boxes = {}
+
+    def box(self, src, dst, seq):
+        with self.lock:
+            return self.boxes.setdefault((src, dst, seq), queue.Queue())
 
 
 class LoopbackComm:
     def __init__(self, fabric: LoopbackFabric, me: int):
         self.f, self.me = fabric, me
+        self.sent = {}
+        self.posted = {}
 
     def exchange(self, send_bufs, recv_bufs, dst, src):
         for s in send_bufs:
-            self.f.q[(self.me, dst)].put(s.clone())
-        return (recv_bufs, src)
+            n = self.sent.get(dst, 0)
+            self.sent[dst] = n + 1
+            self.f.box(self.me, dst, n).put(s.clone())
+        tickets = []
+        for r in recv_bufs:
+            n = self.posted.get(src, 0)
+            self.posted[src] = n + 1
+            tickets.append((r, n))
+        return (tickets, src)
 
     def wait(self, handle):
-        recv_bufs, src = handle
-        for r in recv_bufs:
-            r.copy_(self.f.q[(src, self.me)].get(timeout=120))
+        tickets, src = handle
+        for r, n in tickets:
+            r.copy_(self.f.box(src, self.me, n).get(timeout=120))
 
 
 def run_virtual_ranks(n, fn):
