@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
     constexpr int RPP = 64 / CPR;     // rows per 1-KiB piece (one wave-instruction of the staging)
     constexpr int PPW = (TILEB / 1024) / 4;  // pieces per wave per tile: 4 (d=128) or 2 (d=64)
     constexpr float RESCALE_LOG2 = 8.0f;
+    constexpr float OPTIMISTIC_MAX = 4096.0f;  // largest half-row sum of P the optimistic pass accepts (every P <= 2^12)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* const lds0 = (lds_char*)smem;
@@ -181,6 +182,26 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
             if (t < my_nkt) {
                 const int kb0 = t * BN;
                 const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len);
+                // Optimistic pass: once every row of the wave has a finite running maximum, P is formed
+                // against it WITHOUT looking for the tile's maximum first (a third of the softmax's
+                // instructions).  Scores far below the running maximum just give tiny P; a score far above
+                // it shows up as a large row sum, and only then the exact pass below redoes the tile.
+                bool exact = need_mask || __any(m_run < -1e29f);
+                if (!exact) {
+                    const float mc = m_run * c;
+                    float rs = 0.f;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            float pv = fast_exp2(__builtin_fmaf(s[st][i], c, -mc));
+                            rs += pv;
+                            pf[st][i >> 3][i & 7] = (__bf16)pv;
+                        }
+                    if (__any(!(rs <= OPTIMISTIC_MAX))) exact = true;   // (also catches inf / nan)
+                    else l_run += rs;
+                }
+                if (exact) {
                 if (need_mask) {
 #pragma unroll
                     for (int st = 0; st < 2; ++st)
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
                         pf[st][i >> 3][i & 7] = (__bf16)pv;
                     }
                 l_run += rs;
+                }
             } else {
 #pragma unroll
                 for (int st = 0; st < 2; ++st)

@@ -132,6 +132,29 @@ def test_backward_matches_oracle(name, cu, Hq, Hkv, D, causal):
     assert rel_err(vc.grad, rdv) <= REL_TOL
 
 
+def test_forward_rising_and_falling_scores():
+    """Scores that climb steadily along the keys (the running maximum has to be raised again and
+    again: the optimistic softmax pass keeps falling back to the exact one) and scores that fall
+    steadily (everything after the first tiles is far below the running maximum), d = 128 and 64."""
+    from long_vita_amd import ops
+    for D, T in ((128, 3000), (64, 1500)):
+        g = torch.Generator().manual_seed(5)
+        u = torch.randn(D, generator=g)
+        u = u / u.norm() * (D ** 0.5)
+        ramp = torch.linspace(0.0, 6.0, T)[:, None, None]
+        q = (torch.randn(T, 4, D, generator=g) * 0.2 + 1.5 * u).to(torch.bfloat16)
+        v = torch.randn(T, 2, D, generator=g).to(torch.bfloat16)
+        scale = A.default_scale(D)
+        for sign in (1.0, -1.0):
+            k = (torch.randn(T, 2, D, generator=g) * 0.2 + sign * ramp * u).to(torch.bfloat16)
+            for causal in (True, False):
+                ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, causal)
+                out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, causal)
+                assert rel_err(out, ref_o) <= REL_TOL, (D, sign, causal)
+                err = np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max()
+                assert err <= 2e-3 * max(1.0, np.abs(ref_lse).max() / 10), (D, sign, causal, err)
+
+
 def test_forward_rescale_branch_is_exercised():
     """The kernel defers the running-max update until a row's maximum grows by more than
     2^8; spike two keys so that the update fires in the middle of the key sweep (and a
