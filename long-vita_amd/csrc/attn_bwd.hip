@@ -1,4 +1,7 @@
-// Flash-style attention backward for gfx950 (MI355X), three kernels, no atomics:
+// Flash-style attention backward for gfx950 (MI355X), no atomics.  This file holds the delta kernel,
+// the launcher, and the first generation of the two gradient kernels; the launcher uses the faster
+// second generation by default (attn_bwd_dkdv_rs.hip: role-split dK/dV, attn_bwd_dq_pp.hip: ping-pong
+// dQ) and these only when LVATTN_DKDV_KERNEL=single / LVATTN_DQ_KERNEL=lockstep ask for them.
 //
 // lv_bwd_delta_kernel : delta[h][row] = sum_d dO * O   (fp32)
 //
