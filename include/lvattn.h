@@ -173,6 +173,27 @@ int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, 
             int64_t x_row_stride, int64_t x_head_stride, int64_t o_row_stride, int64_t o_head_stride,
             int64_t tab_rows, int tab_div, int conj, void* stream);
 
+/* ---- InternViT encoder pieces around its GEMMs --------------------------------------
+ * The reference builds the tower from Megatron modules (lcvlm_modellink/core/models/vision/vit_layer_specs.py:80-103:
+ * TENorm / ColumnParallelLinear / MLP with torch.nn.functional.gelu, pretrain_lcvlm.py:191-213) wired by
+ * InternViTTransformerLayer.forward (intern_vit_model.py:32-89) and InternViTModel.forward (:190-261).  All bf16,
+ * fp32 arithmetic, rows of `h` contiguous elements, 16-byte aligned.
+ * lv_layernorm: input_layernorm / pre_mlp_layernorm (:48, :69): y = (x-mean)/sqrt(var+eps)*gamma+beta per row.
+ * lv_bias_gelu: the MLP's activation on linear_fc1's output plus its bias (:72): y = gelu_erf(x + bias).
+ * lv_bias_scale_residual: `residual + (out + bias) * ls` (:59-63, :74-77); bias may be NULL.
+ * lv_patchify: the patch side of conv1 (:139-145, :203-205) as a GEMM operand: [n, c, H, W] ->
+ *   [n*(H/p)*(W/p), kpad], column (ch*p + ky)*p + kx (= conv1.weight.view(out, -1)), zero-padded to kpad.
+ * lv_embed_tokens: class-token concat, conv bias, position embedding and the [b,s,h] -> [s,b,h] permute
+ *   (:207-216, :235-237): proj [n, n_patches, h] -> tokens [n_class + n_patches, n, h]. */
+int lv_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h,
+                 int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream);
+int lv_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, void* stream);
+int lv_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* residual, void* out,
+                           int64_t rows, int h, void* stream);
+int lv_patchify(const void* img, void* patches, int n, int c, int height, int width, int patch, int kpad, void* stream);
+int lv_embed_tokens(const void* proj, const void* conv_bias, const void* class_token, const void* pos_emb, void* tokens,
+                    int n, int n_patches, int n_class, int h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

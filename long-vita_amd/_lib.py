@@ -40,6 +40,11 @@ _SIGNATURES = {
     "lv_pixel_shuffle": (_int, [_vp, _vp, _int, _int, _int, _int, _i64, _vp]),
     "lv_scatter_rows": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp]),
     "lv_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "lv_layernorm": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _f, _vp]),
+    "lv_bias_gelu": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "lv_bias_scale_residual": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "lv_patchify": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "lv_embed_tokens": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "lv_rope": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
 }
 

@@ -424,3 +424,50 @@ extern "C" int lv_rope(const void* x, void* out, const void* cos_tab, const void
                             o_head_stride, tab_rows, tab_div, conj, (hipStream_t)stream);
     return rc ? fail(LV_ELAUNCH, "lv_rope: launch failed") : LV_OK;
 }
+
+// ---------------------------------------------------------------------------
+// InternViT encoder pieces around the GEMMs
+// ---------------------------------------------------------------------------
+static bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+extern "C" int lv_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h,
+                            int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream) {
+    if (!x || !y || !gamma || !beta) return fail(LV_EINVAL, "lv_layernorm: null pointer");
+    if (rows < 0 || h <= 0 || h % 8 || h > 8192) return fail(LV_EINVAL, "lv_layernorm: rows=%lld h=%d (need h %% 8 == 0, h <= 8192)", (long long)rows, h);
+    if (x_row_stride % 8 || y_row_stride % 8 || !al16(x) || !al16(y) || !al16(gamma) || !al16(beta))
+        return fail(LV_EINVAL, "lv_layernorm: rows and parameters must be 16-byte aligned");
+    return lv_launch_layernorm(x, y, gamma, beta, rows, h, x_row_stride, y_row_stride, eps, (hipStream_t)stream)
+               ? fail(LV_ELAUNCH, "lv_layernorm: launch failed") : LV_OK;
+}
+
+extern "C" int lv_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, void* stream) {
+    if (!x || !bias || !y) return fail(LV_EINVAL, "lv_bias_gelu: null pointer");
+    if (rows < 0 || h <= 0 || h % 8 || !al16(x) || !al16(y) || !al16(bias)) return fail(LV_EINVAL, "lv_bias_gelu: h=%d must be a multiple of 8, pointers 16-byte aligned", h);
+    return lv_launch_bias_gelu(x, bias, y, rows, h, (hipStream_t)stream) ? fail(LV_ELAUNCH, "lv_bias_gelu: launch failed") : LV_OK;
+}
+
+extern "C" int lv_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* residual, void* out, int64_t rows,
+                                      int h, void* stream) {
+    if (!x || !ls || !residual || !out) return fail(LV_EINVAL, "lv_bias_scale_residual: null pointer");
+    if (rows < 0 || h <= 0 || h % 8 || !al16(x) || !al16(out) || !al16(ls) || !al16(residual) || (bias && !al16(bias)))
+        return fail(LV_EINVAL, "lv_bias_scale_residual: h=%d must be a multiple of 8, pointers 16-byte aligned", h);
+    return lv_launch_bias_scale_residual(x, bias, ls, residual, out, rows, h, (hipStream_t)stream)
+               ? fail(LV_ELAUNCH, "lv_bias_scale_residual: launch failed") : LV_OK;
+}
+
+extern "C" int lv_patchify(const void* img, void* patches, int n, int c, int height, int width, int patch, int kpad, void* stream) {
+    if (!img || !patches) return fail(LV_EINVAL, "lv_patchify: null pointer");
+    if (n < 0 || c <= 0 || patch <= 0 || height % patch || width % patch || kpad < c * patch * patch)
+        return fail(LV_EINVAL, "lv_patchify: n=%d c=%d %dx%d patch=%d kpad=%d", n, c, height, width, patch, kpad);
+    return lv_launch_patchify(img, patches, n, c, height, width, patch, kpad, (hipStream_t)stream) ? fail(LV_ELAUNCH, "lv_patchify: launch failed") : LV_OK;
+}
+
+extern "C" int lv_embed_tokens(const void* proj, const void* conv_bias, const void* class_token, const void* pos_emb, void* tokens,
+                               int n, int n_patches, int n_class, int h, void* stream) {
+    if (!proj || !conv_bias || !pos_emb || !tokens || (n_class > 0 && !class_token)) return fail(LV_EINVAL, "lv_embed_tokens: null pointer");
+    if (n < 0 || n_patches <= 0 || n_class < 0 || h <= 0 || h % 8) return fail(LV_EINVAL, "lv_embed_tokens: n=%d patches=%d class=%d h=%d", n, n_patches, n_class, h);
+    if (!al16(proj) || !al16(conv_bias) || !al16(pos_emb) || !al16(tokens) || (class_token && !al16(class_token)))
+        return fail(LV_EINVAL, "lv_embed_tokens: pointers must be 16-byte aligned");
+    return lv_launch_embed_tokens(proj, conv_bias, class_token, pos_emb, tokens, n, n_patches, n_class, h, (hipStream_t)stream)
+               ? fail(LV_ELAUNCH, "lv_embed_tokens: launch failed") : LV_OK;
+}

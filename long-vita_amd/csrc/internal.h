@@ -44,3 +44,11 @@ int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows,
 int lv_launch_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, const int32_t* pos_ids, int64_t rows,
                    int heads, int d, int rot, int64_t x_rs, int64_t x_hs, int64_t o_rs, int64_t o_hs, int64_t tab_rows, int tab_div,
                    int conj, hipStream_t stream);
+int lv_launch_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h, int64_t x_rs,
+                        int64_t y_rs, float eps, hipStream_t stream);
+int lv_launch_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, hipStream_t stream);
+int lv_launch_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* res, void* out, int64_t rows, int h,
+                                  hipStream_t stream);
+int lv_launch_patchify(const void* img, void* out, int n, int c, int H, int W, int p, int kpad, hipStream_t stream);
+int lv_launch_embed_tokens(const void* proj, const void* conv_bias, const void* cls, const void* pos, void* out, int n, int np,
+                           int ncls, int h, hipStream_t stream);

@@ -1,0 +1,206 @@
+// Bandwidth-bound pieces of the InternViT encoder around its GEMMs and its attention, for gfx950:
+// LayerNorm, bias + GELU, bias + LayerScale + residual, patch extraction for the 14x14 stride-14
+// convolution (done as a GEMM), and the token assembly (class token, convolution bias, position
+// embedding, [b, s, h] -> [s, b, h]).  bf16 in / out, fp32 arithmetic, 16-byte accesses.
+#include "internal.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dimension: y = (x - mean) / sqrt(var + eps) * gamma + beta.
+// One wave per row; a lane holds CH chunks of 8 columns (h = 512 * CH), kept in registers between the
+// statistics and the normalisation, so x is read once.
+template <int CH>
+__global__ __launch_bounds__(256) void lv_layernorm_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
+                                                            const __bf16* __restrict__ gamma, const __bf16* __restrict__ beta,
+                                                            int64_t rows, int h, int64_t x_rs, int64_t y_rs, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const __bf16* xp = x + row * x_rs;
+    float v[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < h) {
+            bf16x8 t = *reinterpret_cast<const bf16x8*>(xp + col);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[c][i] = (float)t[i]; s += v[c][i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)h;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)h + eps);
+    __bf16* yp = y + row * y_rs;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < h) {
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(gamma + col);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(beta + col);
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (__bf16)((v[c][i] - mean) * rstd * (float)g[i] + (float)b[i]);
+            *reinterpret_cast<bf16x8*>(yp + col) = o;
+        }
+    }
+}
+
+int lv_launch_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h, int64_t x_rs,
+                        int64_t y_rs, float eps, hipStream_t stream) {
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int ch = (h + 511) / 512;
+#define LV_LN(CH) hipLaunchKernelGGL((lv_layernorm_kernel<CH>), grid, block, 0, stream, (const __bf16*)x, (__bf16*)y, \
+                                     (const __bf16*)gamma, (const __bf16*)beta, rows, h, x_rs, y_rs, eps)
+    if (ch <= 1) LV_LN(1); else if (ch <= 2) LV_LN(2); else if (ch <= 4) LV_LN(4); else if (ch <= 8) LV_LN(8); else LV_LN(16);
+#undef LV_LN
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------
+// y = gelu(x + bias), the exact (erf) form torch.nn.functional.gelu defaults to.
+__global__ __launch_bounds__(256) void lv_bias_gelu_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ bias,
+                                                            __bf16* __restrict__ y, int64_t rows, int h) {
+    const int cpr = h / 8;
+    const int64_t total = rows * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % cpr) * 8;
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + idx * 8);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bias + col);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = (float)t[i] + (float)b[i];
+            o[i] = (__bf16)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
+        }
+        *reinterpret_cast<bf16x8*>(y + idx * 8) = o;
+    }
+}
+
+// out = residual + (x + bias) * ls   (LayerScale; bias may be null)
+__global__ __launch_bounds__(256) void lv_bias_scale_residual_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ bias,
+                                                                      const __bf16* __restrict__ ls, const __bf16* __restrict__ res,
+                                                                      __bf16* __restrict__ out, int64_t rows, int h) {
+    const int cpr = h / 8;
+    const int64_t total = rows * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % cpr) * 8;
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + idx * 8);
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + idx * 8);
+        const bf16x8 s = *reinterpret_cast<const bf16x8*>(ls + col);
+        bf16x8 b;
+        if (bias) b = *reinterpret_cast<const bf16x8*>(bias + col);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = (float)t[i] + (bias ? (float)b[i] : 0.f);
+            o[i] = (__bf16)((float)r[i] + v * (float)s[i]);
+        }
+        *reinterpret_cast<bf16x8*>(out + idx * 8) = o;
+    }
+}
+
+static unsigned stride_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (unsigned)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));
+}
+
+int lv_launch_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, hipStream_t stream) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(lv_bias_gelu_kernel, dim3(stride_grid(rows * (h / 8))), dim3(256), 0, stream, (const __bf16*)x,
+                       (const __bf16*)bias, (__bf16*)y, rows, h);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int lv_launch_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* res, void* out, int64_t rows, int h,
+                                  hipStream_t stream) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(lv_bias_scale_residual_kernel, dim3(stride_grid(rows * (h / 8))), dim3(256), 0, stream, (const __bf16*)x,
+                       (const __bf16*)bias, (const __bf16*)ls, (const __bf16*)res, (__bf16*)out, rows, h);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------
+// Patch extraction: img [n, c, H, W] bf16 -> patches [n * gh * gw, kpad] with column
+// (ch * p + ky) * p + kx  (the order of a Conv2d weight [out, c, p, p] flattened), zero-padded to kpad.
+__global__ __launch_bounds__(256) void lv_patchify_kernel(const __bf16* __restrict__ img, __bf16* __restrict__ out, int n, int c,
+                                                           int H, int W, int p, int kpad) {
+    const int gh = H / p, gw = W / p;
+    const int64_t total = (int64_t)n * gh * gw * kpad;
+    const int k = c * p * p;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % kpad);
+        const int64_t tok = idx / kpad;
+        __bf16 v = (__bf16)0.f;
+        if (col < k) {
+            const int kx = col % p, ky = (col / p) % p, ch = col / (p * p);
+            const int px = (int)(tok % gw), py = (int)((tok / gw) % gh);
+            const int64_t im = tok / ((int64_t)gw * gh);
+            v = img[((im * c + ch) * H + (py * p + ky)) * (int64_t)W + px * p + kx];
+        }
+        out[idx] = v;
+    }
+}
+
+int lv_launch_patchify(const void* img, void* out, int n, int c, int H, int W, int p, int kpad, hipStream_t stream) {
+    const int64_t total = (int64_t)n * (H / p) * (W / p) * kpad;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(lv_patchify_kernel, dim3(stride_grid(total)), dim3(256), 0, stream, (const __bf16*)img, (__bf16*)out, n, c, H, W,
+                       p, kpad);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Token assembly: tokens [s, n, h] (sequence-major) from the patch GEMM output proj [n, np, h]:
+//   s < ncls : class_token[s] + pos[s]         s >= ncls : proj[n][s - ncls] + conv_bias + pos[s]
+__global__ __launch_bounds__(256) void lv_embed_tokens_kernel(const __bf16* __restrict__ proj, const __bf16* __restrict__ conv_bias,
+                                                               const __bf16* __restrict__ cls, const __bf16* __restrict__ pos,
+                                                               __bf16* __restrict__ out, int n, int np, int ncls, int h) {
+    const int cpr = h / 8;
+    const int s_len = np + ncls;
+    const int64_t total = (int64_t)s_len * n * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % cpr) * 8;
+        const int64_t sn = idx / cpr;
+        const int im = (int)(sn % n);
+        const int s = (int)(sn / n);
+        const bf16x8 pe = *reinterpret_cast<const bf16x8*>(pos + (int64_t)s * h + col);
+        bf16x8 o;
+        if (s < ncls) {
+            const bf16x8 ct = *reinterpret_cast<const bf16x8*>(cls + (int64_t)s * h + col);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (__bf16)((float)ct[i] + (float)pe[i]);
+        } else {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(proj + ((int64_t)im * np + (s - ncls)) * h + col);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(conv_bias + col);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (__bf16)((float)t[i] + (float)b[i] + (float)pe[i]);
+        }
+        *reinterpret_cast<bf16x8*>(out + idx * 8) = o;
+    }
+}
+
+int lv_launch_embed_tokens(const void* proj, const void* conv_bias, const void* cls, const void* pos, void* out, int n, int np,
+                           int ncls, int h, hipStream_t stream) {
+    const int64_t total = (int64_t)(np + ncls) * n * (h / 8);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(lv_embed_tokens_kernel, dim3(stride_grid(total)), dim3(256), 0, stream, (const __bf16*)proj,
+                       (const __bf16*)conv_bias, (const __bf16*)cls, (const __bf16*)pos, (__bf16*)out, n, np, ncls, h);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

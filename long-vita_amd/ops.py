@@ -324,3 +324,74 @@ class _Rope(torch.autograd.Function):
 def rope(x: torch.Tensor, cos_tab: torch.Tensor, sin_tab: torch.Tensor, pos_ids: torch.Tensor | None = None, tab_div: int = 1):
     """Differentiable rotary embedding of x [rows, heads, d] (see rope_launch)."""
     return _Rope.apply(x, cos_tab, sin_tab, pos_ids, int(tab_div))
+
+
+# ---------------------------------------------------------------------------
+# InternViT encoder pieces around the GEMMs
+# ---------------------------------------------------------------------------
+def _bf16_2d(t: torch.Tensor, what: str) -> torch.Tensor:
+    _require_gpu(t)
+    if t.dtype != torch.bfloat16:
+        raise LvAttnError(f"{what} expects bfloat16")
+    return t
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm over the last dimension of x [..., h] (bf16, fp32 statistics)."""
+    _bf16_2d(x, "layernorm")
+    h = x.shape[-1]
+    x2 = x.reshape(-1, h)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], h), dtype=x.dtype, device=x.device)
+    check(_lib.lib().lv_layernorm(_ptr(x2), _ptr(y), _ptr(gamma.contiguous()), _ptr(beta.contiguous()), x2.shape[0], h,
+                                  x2.stride(0), y.stride(0), float(eps), _stream()), "lv_layernorm")
+    return y.view(x.shape)
+
+
+def bias_gelu(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """gelu(x + bias), erf form, x [..., h] contiguous bf16."""
+    _bf16_2d(x, "bias_gelu")
+    x = x.contiguous()
+    h = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.lib().lv_bias_gelu(_ptr(x), _ptr(bias.contiguous()), _ptr(y), x.numel() // h, h, _stream()), "lv_bias_gelu")
+    return y
+
+
+def bias_scale_residual(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    """residual + (x + bias) * ls with per-column bias / ls, all [..., h] contiguous bf16."""
+    _bf16_2d(x, "bias_scale_residual")
+    x, residual = x.contiguous(), residual.contiguous()
+    if residual.shape != x.shape:
+        raise LvAttnError("bias_scale_residual: x and residual differ in shape")
+    h = x.shape[-1]
+    out = torch.empty_like(x)
+    check(_lib.lib().lv_bias_scale_residual(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(ls.contiguous()),
+                                            _ptr(residual), _ptr(out), x.numel() // h, h, _stream()), "lv_bias_scale_residual")
+    return out
+
+
+def patchify(img: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
+    """[n, c, H, W] bf16 -> [n * (H/patch) * (W/patch), kpad] rows in Conv2d-weight column order."""
+    _bf16_2d(img, "patchify")
+    img = img.contiguous()
+    n, c, H, W = img.shape
+    out = torch.empty((n * (H // patch) * (W // patch), kpad), dtype=img.dtype, device=img.device)
+    check(_lib.lib().lv_patchify(_ptr(img), _ptr(out), n, c, H, W, patch, kpad, _stream()), "lv_patchify")
+    return out
+
+
+def embed_tokens(proj: torch.Tensor, conv_bias: torch.Tensor, class_token: torch.Tensor | None, pos_emb: torch.Tensor) -> torch.Tensor:
+    """proj [n, n_patches, h] -> tokens [n_class + n_patches, n, h] = cat(class_token, proj + conv_bias) + pos_emb."""
+    _bf16_2d(proj, "embed_tokens")
+    proj = proj.contiguous()
+    n, npatch, h = proj.shape
+    ncls = 0 if class_token is None else class_token.reshape(-1, h).shape[0]
+    if pos_emb.shape[0] < npatch + ncls:
+        raise LvAttnError("embed_tokens: position table shorter than the token sequence")
+    out = torch.empty((npatch + ncls, n, h), dtype=proj.dtype, device=proj.device)
+    check(_lib.lib().lv_embed_tokens(_ptr(proj), _ptr(conv_bias.contiguous()),
+                                     _ptr(class_token.reshape(-1, h).contiguous() if class_token is not None else None),
+                                     _ptr(pos_emb.contiguous()), _ptr(out), n, npatch, ncls, h, _stream()), "lv_embed_tokens")
+    return out

@@ -24,6 +24,8 @@ Fixtures written:
   packing.npz          Qwen2Dataset.add_ret / process_ret (cognitron_vl/data/dataset_qwen2.py)
   rope.npz             RotaryEmbedding.forward angle tables (incl. packed position ids),
                        apply_rotary_pos_emb_bshd / _thd on bf16 tensors (rotary_pos_embedding.py)
+  vit.npz              InternViTTransformerLayer.forward / InternViTModel.forward (intern_vit_model.py)
+                       run over the oracle's restatement of the Megatron submodules
 """
 from __future__ import annotations
 
@@ -375,9 +377,82 @@ def gen_rope():
     print("rope.npz:", len(out), "arrays")
 
 
+def gen_vit():
+    """The reference's own layer and model ``forward`` (intern_vit_model.py:32-89, :190-261), called unbound on
+    namespaces whose submodules (LayerNorm, SelfAttention, MLP: Megatron classes that are not installed) are the
+    oracle's restatements.  What this pins is the wiring those two functions do: the order of the norms, where
+    the two biases are added, LayerScale and residuals, the patch projection / class token / position embedding
+    and the [b,s,h] <-> [s,b,h] permutes."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import vit_ref
+    ivm = importlib.import_module("lcvlm_modellink.core.models.vision.intern_vit_model")
+    ivm.make_viewless_tensor = lambda inp, requires_grad, keep_graph: inp
+    ivm.mpu = ns(get_context_parallel_world_size=lambda: 1, get_context_parallel_rank=lambda: 0)
+    g = torch.Generator().manual_seed(4242)
+    h, heads, ffn, n_layers, patch, img_hw, n, eps = 128, 2, 160, 2, 14, 42, 2, 1e-6  # head dim 64: a size the device kernels take
+    seq = (img_hw // patch) ** 2 + 1
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+    sd = {"conv1.weight": rnd(h, 3, patch, patch, scale=0.05), "conv1.bias": rnd(h, scale=0.1),
+          "class_token": rnd(1, 1, h), "position_embeddings.weight": rnd(seq, h, scale=0.2)}
+    for i in range(n_layers):
+        pre = f"decoder.layers.{i}."
+        sd[pre + "input_layernorm.weight"] = 1 + rnd(h, scale=0.1)
+        sd[pre + "input_layernorm.bias"] = rnd(h, scale=0.1)
+        sd[pre + "self_attention.linear_qkv.weight"] = rnd(3 * h, h, scale=0.15)
+        sd[pre + "self_attention.linear_qkv.bias"] = rnd(3 * h, scale=0.1)
+        sd[pre + "self_attention.linear_proj.weight"] = rnd(h, h, scale=0.15)
+        sd[pre + "self_attention.linear_proj.bias"] = rnd(h, scale=0.1)
+        sd[pre + "pre_mlp_layernorm.weight"] = 1 + rnd(h, scale=0.1)
+        sd[pre + "pre_mlp_layernorm.bias"] = rnd(h, scale=0.1)
+        sd[pre + "mlp.linear_fc1.weight"] = rnd(ffn, h, scale=0.15)
+        sd[pre + "mlp.linear_fc1.bias"] = rnd(ffn, scale=0.1)
+        sd[pre + "mlp.linear_fc2.weight"] = rnd(h, ffn, scale=0.15)
+        sd[pre + "mlp.linear_fc2.bias"] = rnd(h, scale=0.1)
+        sd[pre + "ls1"] = rnd(h, scale=0.5)   # larger than the 0.01 initial value so the branches matter
+        sd[pre + "ls2"] = rnd(h, scale=0.5)
+
+    def layer_ns(i):
+        pre = f"decoder.layers.{i}."
+        p = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        sub = lambda name: {k[len(name) + 1:]: v for k, v in p.items() if k.startswith(name + ".")}
+        return ns(input_layernorm=lambda x: vit_ref.layer_norm(x, p["input_layernorm.weight"], p["input_layernorm.bias"], eps),
+                  pre_mlp_layernorm=lambda x: vit_ref.layer_norm(x, p["pre_mlp_layernorm.weight"], p["pre_mlp_layernorm.bias"], eps),
+                  self_attention=lambda x, **kw: vit_ref.self_attention(x, sub("self_attention"), heads),
+                  mlp=lambda x: vit_ref.mlp(x, sub("mlp")), ls1=p["ls1"], ls2=p["ls2"])
+
+    layer_fwd = ivm.InternViTTransformerLayer.forward
+    out = {"meta": np.array([h, heads, ffn, n_layers, patch, img_hw, n], dtype=np.int64), "eps": np.array(eps)}
+    for k, v in sd.items():
+        out["sd." + k] = v.numpy()
+    x = rnd(seq, n, h)
+    out["layer0.in"] = x.numpy()
+    y, _ = layer_fwd(layer_ns(0), x, None)
+    out["layer0.out"] = y.numpy()
+
+    conv = torch.nn.Conv2d(3, h, kernel_size=patch, stride=patch, bias=True)
+    conv.weight.data.copy_(sd["conv1.weight"]); conv.bias.data.copy_(sd["conv1.bias"])
+    pos = torch.nn.Embedding(seq, h); pos.weight.data.copy_(sd["position_embeddings.weight"])
+
+    def decoder(x, mask):
+        for i in range(n_layers):
+            x, _ = layer_fwd(layer_ns(i), x, mask)
+        return x
+    self = ns(conv1=conv, add_class_token=True, class_token=sd["class_token"], seq_length=seq, position_embeddings=pos,
+              position_ids=torch.arange(seq).expand(1, -1), vision_context_parallel=False, decoder=decoder)
+    img = rnd(n, 3, img_hw, img_hw)
+    out["model.img"] = img.numpy()
+    with torch.no_grad():
+        out["model.out"] = ivm.InternViTModel.forward(self, img).numpy()
+    np.savez_compressed(os.path.join(HERE, "vit.npz"), **out)
+    print("vit.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     install_shim()
-    which = sys.argv[1:] or ["eager", "indexing", "packing", "rope"]
+    which = sys.argv[1:] or ["eager", "indexing", "packing", "rope", "vit"]
     if "eager" in which:
         gen_eager_attention()
     if "indexing" in which:
@@ -386,3 +461,5 @@ if __name__ == "__main__":
         gen_packing()
     if "rope" in which:
         gen_rope()
+    if "vit" in which:
+        gen_vit()

@@ -1,0 +1,141 @@
+"""InternViT forward on the device (HIP kernels through the C ABI + library GEMMs) against the oracle and the
+fixture made by the reference's own layer / model forward.  Tolerance: max error <= 2e-2 of the output's
+largest magnitude (bf16 activations on the device, fp32 in the oracle)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+
+
+def _close(got: torch.Tensor, want: torch.Tensor, tol=TOL):
+    got, want = got.float().cpu(), want.float().cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= tol * want.abs().max().item(), f"max err {err} vs scale {want.abs().max().item()}"
+
+
+def _bf(*shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("rows,h", [(1, 8), (77, 1024), (513, 4096), (5, 200), (3, 8192)])
+def test_layernorm(rows, h):
+    from long_vita_amd import ops
+    x, w, b = _bf(rows, h, seed=1, scale=3.0) + 0.5, 1 + _bf(h, seed=2, scale=0.2), _bf(h, seed=3, scale=0.2)
+    y = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+    want = vit_ref.layer_norm(x, w, b, 1e-6)
+    # one bf16 rounding of the result: half an ulp relative (2^-9) on each element
+    assert torch.all((y.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6)
+
+
+def test_layernorm_strided_rows_and_constant_row():
+    from long_vita_amd import ops
+    buf = _bf(9, 3 * 256, seed=4).cuda()
+    buf[4, 256:512] = 2.5     # zero variance: output is exactly beta
+    w, b = 1 + _bf(256, seed=5, scale=0.2), _bf(256, seed=6, scale=0.2)
+    y = ops.layernorm(buf[:, 256:512], w.cuda(), b.cuda(), 1e-5)
+    want = vit_ref.layer_norm(buf[:, 256:512].cpu(), w, b, 1e-5)
+    _close(y, want, 2.0 ** -7)
+    assert torch.equal(y[4].cpu(), b)
+
+
+def test_bias_gelu_and_bias_scale_residual():
+    from long_vita_amd import ops
+    rows, h = 131, 4096
+    x, bias = _bf(rows, h, seed=7, scale=2.0), _bf(h, seed=8)
+    y = ops.bias_gelu(x.cuda(), bias.cuda())
+    want = vit_ref.gelu(x.float() + bias.float())
+    assert torch.all((y.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6)
+    ls, res = _bf(h, seed=9, scale=0.1), _bf(rows, h, seed=10)
+    out = ops.bias_scale_residual(x.cuda(), bias.cuda(), ls.cuda(), res.cuda())
+    want = res.float() + (x.float() + bias.float()) * ls.float()
+    assert torch.all((out.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6)
+    out = ops.bias_scale_residual(x.cuda(), None, ls.cuda(), res.cuda())
+    want = res.float() + x.float() * ls.float()
+    assert torch.all((out.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6)
+
+
+def test_patchify_is_the_conv_unfold_bit_exact():
+    from long_vita_amd import ops
+    n, c, hw, p = 3, 3, 56, 14
+    img = _bf(n, c, hw, hw, seed=11)
+    kpad = 592
+    got = ops.patchify(img.cuda(), p, kpad).cpu()
+    want = torch.nn.functional.unfold(img.float(), kernel_size=p, stride=p).permute(0, 2, 1).reshape(-1, c * p * p)
+    assert torch.equal(got[:, : c * p * p].float(), want)
+    assert torch.count_nonzero(got[:, c * p * p:]) == 0
+
+
+def test_embed_tokens():
+    from long_vita_amd import ops
+    n, npatch, h = 3, 16, 256
+    proj, cb, cls, pos = _bf(n, npatch, h, seed=12), _bf(h, seed=13), _bf(1, 1, h, seed=14), _bf(npatch + 1, h, seed=15)
+    got = ops.embed_tokens(proj.cuda(), cb.cuda(), cls.cuda(), pos.cuda())
+    want = torch.cat([cls.float().expand(n, -1, -1), proj.float() + cb.float()], dim=1) + pos.float()[None]
+    want = want.permute(1, 0, 2)
+    assert got.shape == (npatch + 1, n, h)
+    assert torch.all((got.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6)
+
+
+def _golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vit.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    return g, sd
+
+
+def _model(cfg_kwargs, sd):
+    from long_vita_amd import intern_vit as iv
+    m = iv.InternViTModel(iv.InternViTConfig(**cfg_kwargs))
+    m.load_state_dict(sd, strict=True)
+    return m.to(torch.bfloat16).cuda()
+
+
+def test_layer_and_model_against_reference_fixture(golden_dir):
+    from long_vita_amd import ops
+    g, sd = _golden(golden_dir)
+    h, heads, ffn, n_layers, patch, img_hw, n = (int(v) for v in g["meta"])
+    m = _model(dict(hidden_size=h, ffn_hidden_size=ffn, num_attention_heads=heads, num_layers=n_layers, patch_dim=patch,
+                    img_h=img_hw, img_w=img_hw, layernorm_epsilon=float(g["eps"])), sd)
+    x = torch.from_numpy(g["layer0.in"]).to(torch.bfloat16).cuda()
+    desc = ops.blocks_on_device([0, x.shape[0]], False, False, x.device)
+    with torch.no_grad():
+        y = m.decoder.layers[0](x, desc)
+    _close(y, torch.from_numpy(g["layer0.out"]))
+    out = m(torch.from_numpy(g["model.img"]).to(torch.bfloat16).cuda())
+    _close(out, torch.from_numpy(g["model.out"]))
+
+
+def test_model_at_internvit_width_against_oracle():
+    """hidden 1024 / 16 heads / ffn 4096 as shipped, 3 layers and 112-pixel tiles to keep the oracle quick."""
+    from long_vita_amd import intern_vit as iv
+    cfg = iv.InternViTConfig(num_layers=3, img_h=112, img_w=112)
+    torch.manual_seed(5)
+    m = iv.InternViTModel(cfg)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("ls1") or name.endswith("ls2"):
+                p.copy_(torch.randn_like(p) * 0.3)
+            elif "layernorm" in name and name.endswith("weight"):
+                p.copy_(1 + 0.1 * torch.randn_like(p))
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+        m = m.to(torch.bfloat16)
+    sd = {k: v.detach().float() for k, v in m.state_dict().items()}
+    img = _bf(5, 3, 112, 112, seed=21)
+    want = vit_ref.model_forward(img.float(), sd, cfg.num_attention_heads, cfg.patch_dim, cfg.layernorm_epsilon)
+    got = m.cuda()(img.cuda())
+    assert got.shape == (5, 65, 1024)
+    _close(got, want)
+
+
+def test_rejects_what_it_does_not_build():
+    from long_vita_amd import intern_vit as iv
+    with pytest.raises(NotImplementedError):
+        iv.InternViTModel(iv.InternViTConfig(num_layers=1), vision_context_parallel=True)
