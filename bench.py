@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line: metric tokens/s for the whole job, plus
                timed on the host cores on a bounded row sample, extrapolated.
 
 Other workloads (``cfg3_fwd_bwd``: 128K packed tokens forward+backward; ``rope_qk``: rotary embedding of Q and K;
-``cfg2_vit``: InternViT-300M attention on 64 frames) are for profiling; the
+``cfg2_vit``: InternViT-300M attention on 64 frames; ``vit_tower``: the whole InternViT-300M encoder forward on 64 tiles) are for profiling; the
 judged line is the default one.
 """
 from __future__ import annotations
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "rope_qk"])
+    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "vit_tower", "rope_qk"])
     ap.add_argument("--seq", type=int, default=0, help="override the sequence length (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -236,6 +236,28 @@ def main():
         hbm_bytes_per_step = 2.0 * S * (HQ + HKV) * D * 2 + 2.0 * 2 * S * D * 2   # x read + written; both tables once per tensor
         flops_per_step = flops_per_gpu_step = 0.0
         config = {"workload": "rope_qk: rotary embedding of Q [S,40,128] and K [S,8,128], in place", "seq_len": S}
+        scaling = "weak"
+    elif wl == "vit_tower":  # the whole frozen InternViT-300M encoder on 64 tiles of 448 x 448 (random weights)
+        from long_vita_amd import intern_vit as iv
+        B = 64
+        cfg = iv.InternViTConfig()
+        torch.manual_seed(1)
+        tower = iv.InternViTModel(cfg).to(torch.bfloat16).to(dev)
+        img = rnd(B, 3, cfg.img_h, cfg.img_w)
+
+        def step():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tower(img)
+            e1.record()
+            return e0, e1
+        Sv, hd, ffn = tower.seq_length, cfg.hidden_size, cfg.ffn_hidden_size
+        tokens_per_step = B * Sv
+        per_token = 2.0 * hd * (4 * hd + 2 * ffn) + 4.0 * Sv * hd
+        flops_per_step = cfg.num_layers * B * Sv * per_token + B * tower.num_patches * 2.0 * 3 * cfg.patch_dim ** 2 * hd
+        flops_per_gpu_step = flops_per_step
+        config = {"workload": "vit_tower: InternViT-300M encoder forward (24 layers, GEMMs + attention + fused elementwise), 64 tiles of 448x448",
+                  "tiles": B, "seq_len": Sv, "hidden": hd, "layers": cfg.num_layers}
         scaling = "weak"
     else:  # cfg2_vit: 24 layers x 64 frames x 16 heads x 1025 tokens, d=64, non-causal
         B, H, Sv, Dv, layers = 64, 16, 1025, 64, 24

@@ -179,7 +179,12 @@ int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, 
  * InternViTTransformerLayer.forward (intern_vit_model.py:32-89) and InternViTModel.forward (:190-261).  All bf16,
  * fp32 arithmetic, rows of `h` contiguous elements, 16-byte aligned.
  * lv_layernorm: input_layernorm / pre_mlp_layernorm (:48, :69): y = (x-mean)/sqrt(var+eps)*gamma+beta per row.
- * lv_bias_gelu: the MLP's activation on linear_fc1's output plus its bias (:72): y = gelu_erf(x + bias).
+ * lv_bias_gelu: the MLP's activation on linear_fc1's output plus its bias (:72): y = gelu_erf(x + bias); bias may be
+ *   NULL (the projector's MLP has none, pretrain_lcvlm.py:394).
+ * lv_bias_gelu_bwd / lv_layernorm_bwd: the gradients torch autograd derives for those two in the reference (the
+ *   projector of pretrain_lcvlm.py:431-451 trains in every stage): dx = dy * gelu'(x + bias); LayerNorm dx plus
+ *   dgamma_dbeta [2, h] fp32 (dgamma then dbeta), summed over rows in a fixed order through `workspace`
+ *   (lv_layernorm_bwd_workspace_bytes(rows, h) bytes of device memory, contents undefined afterwards).
  * lv_bias_scale_residual: `residual + (out + bias) * ls` (:59-63, :74-77); bias may be NULL.
  * lv_patchify: the patch side of conv1 (:139-145, :203-205) as a GEMM operand: [n, c, H, W] ->
  *   [n*(H/p)*(W/p), kpad], column (ch*p + ky)*p + kx (= conv1.weight.view(out, -1)), zero-padded to kpad.
@@ -188,6 +193,11 @@ int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, 
 int lv_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h,
                  int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream);
 int lv_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, void* stream);
+int lv_bias_gelu_bwd(const void* x, const void* bias, const void* dy, void* dx, int64_t rows, int h, void* stream);
+int64_t lv_layernorm_bwd_workspace_bytes(int64_t rows, int h);
+int lv_layernorm_bwd(const void* x, const void* dy, const void* gamma, void* dx, float* dgamma_dbeta, void* workspace,
+                     int64_t workspace_bytes, int64_t rows, int h, int64_t x_row_stride, int64_t dy_row_stride,
+                     int64_t dx_row_stride, float eps, void* stream);
 int lv_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* residual, void* out,
                            int64_t rows, int h, void* stream);
 int lv_patchify(const void* img, void* patches, int n, int c, int height, int width, int patch, int kpad, void* stream);

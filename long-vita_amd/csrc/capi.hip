@@ -441,9 +441,38 @@ extern "C" int lv_layernorm(const void* x, void* y, const void* gamma, const voi
 }
 
 extern "C" int lv_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, void* stream) {
-    if (!x || !bias || !y) return fail(LV_EINVAL, "lv_bias_gelu: null pointer");
-    if (rows < 0 || h <= 0 || h % 8 || !al16(x) || !al16(y) || !al16(bias)) return fail(LV_EINVAL, "lv_bias_gelu: h=%d must be a multiple of 8, pointers 16-byte aligned", h);
+    if (!x || !y) return fail(LV_EINVAL, "lv_bias_gelu: null pointer");
+    if (rows < 0 || h <= 0 || h % 8 || !al16(x) || !al16(y) || (bias && !al16(bias))) return fail(LV_EINVAL, "lv_bias_gelu: h=%d must be a multiple of 8, pointers 16-byte aligned", h);
     return lv_launch_bias_gelu(x, bias, y, rows, h, (hipStream_t)stream) ? fail(LV_ELAUNCH, "lv_bias_gelu: launch failed") : LV_OK;
+}
+
+extern "C" int lv_bias_gelu_bwd(const void* x, const void* bias, const void* dy, void* dx, int64_t rows, int h, void* stream) {
+    if (!x || !dy || !dx) return fail(LV_EINVAL, "lv_bias_gelu_bwd: null pointer");
+    if (rows < 0 || h <= 0 || h % 8 || !al16(x) || !al16(dy) || !al16(dx) || (bias && !al16(bias)))
+        return fail(LV_EINVAL, "lv_bias_gelu_bwd: h=%d must be a multiple of 8, pointers 16-byte aligned", h);
+    return lv_launch_bias_gelu_bwd(x, bias, dy, dx, rows, h, (hipStream_t)stream) ? fail(LV_ELAUNCH, "lv_bias_gelu_bwd: launch failed") : LV_OK;
+}
+
+extern "C" int64_t lv_layernorm_bwd_workspace_bytes(int64_t rows, int h) {
+    if (rows < 0 || h <= 0) return 0;
+    return (int64_t)lv_layernorm_bwd_parts(rows) * 2 * h * (int64_t)sizeof(float);
+}
+
+extern "C" int lv_layernorm_bwd(const void* x, const void* dy, const void* gamma, void* dx, float* dgamma_dbeta, void* workspace,
+                                int64_t workspace_bytes, int64_t rows, int h, int64_t x_row_stride, int64_t dy_row_stride,
+                                int64_t dx_row_stride, float eps, void* stream) {
+    if (!x || !dy || !gamma || !dx || !dgamma_dbeta || !workspace) return fail(LV_EINVAL, "lv_layernorm_bwd: null pointer");
+    if (rows <= 0 || h <= 0 || h % 8 || h > 4096)
+        return fail(LV_EINVAL, "lv_layernorm_bwd: rows=%lld h=%d (need rows > 0, h %% 8 == 0, h <= 4096)", (long long)rows, h);
+    if (x_row_stride % 8 || dy_row_stride % 8 || dx_row_stride % 8 || !al16(x) || !al16(dy) || !al16(dx) || !al16(gamma) ||
+        !al16(dgamma_dbeta) || !al16(workspace))
+        return fail(LV_EINVAL, "lv_layernorm_bwd: rows, parameters and workspace must be 16-byte aligned");
+    if (workspace_bytes < lv_layernorm_bwd_workspace_bytes(rows, h))
+        return fail(LV_EINVAL, "lv_layernorm_bwd: workspace of %lld bytes, need %lld", (long long)workspace_bytes,
+                    (long long)lv_layernorm_bwd_workspace_bytes(rows, h));
+    return lv_launch_layernorm_bwd(x, dy, gamma, dx, dgamma_dbeta, (float*)workspace, rows, h, x_row_stride, dy_row_stride,
+                                   dx_row_stride, eps, (hipStream_t)stream)
+               ? fail(LV_ELAUNCH, "lv_layernorm_bwd: launch failed") : LV_OK;
 }
 
 extern "C" int lv_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* residual, void* out, int64_t rows,

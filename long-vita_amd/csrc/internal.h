@@ -47,6 +47,10 @@ int lv_launch_rope(const void* x, void* out, const void* cos_tab, const void* si
 int lv_launch_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h, int64_t x_rs,
                         int64_t y_rs, float eps, hipStream_t stream);
 int lv_launch_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, hipStream_t stream);
+int lv_launch_bias_gelu_bwd(const void* x, const void* bias, const void* dy, void* dx, int64_t rows, int h, hipStream_t stream);
+int lv_layernorm_bwd_parts(int64_t rows);
+int lv_launch_layernorm_bwd(const void* x, const void* dy, const void* gamma, void* dx, float* dgamma_dbeta, float* part,
+                            int64_t rows, int h, int64_t x_rs, int64_t dy_rs, int64_t dx_rs, float eps, hipStream_t stream);
 int lv_launch_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* res, void* out, int64_t rows, int h,
                                   hipStream_t stream);
 int lv_launch_patchify(const void* img, void* out, int n, int c, int H, int W, int p, int kpad, hipStream_t stream);

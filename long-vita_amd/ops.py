@@ -336,8 +336,8 @@ def _bf16_2d(t: torch.Tensor, what: str) -> torch.Tensor:
     return t
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
-    """LayerNorm over the last dimension of x [..., h] (bf16, fp32 statistics)."""
+def layernorm_launch(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm over the last dimension of x [..., h] (bf16, fp32 statistics); no autograd."""
     _bf16_2d(x, "layernorm")
     h = x.shape[-1]
     x2 = x.reshape(-1, h)
@@ -349,14 +349,88 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y.view(x.shape)
 
 
-def bias_gelu(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """gelu(x + bias), erf form, x [..., h] contiguous bf16."""
+def layernorm_bwd_launch(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float):
+    """Gradients of ``layernorm_launch``: (dx like x, dgamma [h] fp32, dbeta [h] fp32)."""
+    _bf16_2d(x, "layernorm_bwd")
+    h = x.shape[-1]
+    x2, dy2 = x.reshape(-1, h), dy.reshape(-1, h)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if dy2.stride(1) != 1 or dy2.dtype != x.dtype:
+        dy2 = dy2.to(x.dtype).contiguous()
+    rows = x2.shape[0]
+    dx = torch.empty((rows, h), dtype=x.dtype, device=x.device)
+    dgb = torch.empty((2, h), dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().lv_layernorm_bwd_workspace_bytes(rows, h)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().lv_layernorm_bwd(_ptr(x2), _ptr(dy2), _ptr(gamma.contiguous()), _ptr(dx), _ptr(dgb), _ptr(ws), nbytes, rows, h,
+                                      x2.stride(0), dy2.stride(0), dx.stride(0), float(eps), _stream()), "lv_layernorm_bwd")
+    return dx.view(x.shape), dgb[0], dgb[1]
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        ctx.param_dtypes = (gamma.dtype, beta.dtype)
+        return layernorm_launch(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd_launch(x, dy, gamma, ctx.eps)
+        return dx, dg.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1]), None
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm over the last dimension of x [..., h] (bf16 data and parameters, fp32 statistics), differentiable."""
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad or beta.requires_grad):
+        return _LayerNorm.apply(x, gamma, beta, eps)
+    return layernorm_launch(x, gamma, beta, eps)
+
+
+def bias_gelu_launch(x: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
     _bf16_2d(x, "bias_gelu")
     x = x.contiguous()
     h = x.shape[-1]
     y = torch.empty_like(x)
-    check(_lib.lib().lv_bias_gelu(_ptr(x), _ptr(bias.contiguous()), _ptr(y), x.numel() // h, h, _stream()), "lv_bias_gelu")
+    check(_lib.lib().lv_bias_gelu(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(y), x.numel() // h, h,
+                                  _stream()), "lv_bias_gelu")
     return y
+
+
+def bias_gelu_bwd_launch(x: torch.Tensor, bias: torch.Tensor | None, dy: torch.Tensor) -> torch.Tensor:
+    _bf16_2d(x, "bias_gelu_bwd")
+    x, dy = x.contiguous(), dy.to(x.dtype).contiguous()
+    h = x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_lib.lib().lv_bias_gelu_bwd(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(dy), _ptr(dx),
+                                      x.numel() // h, h, _stream()), "lv_bias_gelu_bwd")
+    return dx
+
+
+class _BiasGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        ctx.save_for_backward(x, bias)
+        return bias_gelu_launch(x, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias = ctx.saved_tensors
+        dx = bias_gelu_bwd_launch(x, bias, dy)
+        dbias = None
+        if bias is not None and ctx.needs_input_grad[1]:
+            dbias = dx.reshape(-1, dx.shape[-1]).sum(0, dtype=torch.float32).to(bias.dtype)
+        return dx, dbias
+
+
+def bias_gelu(x: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """gelu(x + bias), erf form, x [..., h] contiguous bf16; bias may be None; differentiable."""
+    if torch.is_grad_enabled() and (x.requires_grad or (bias is not None and bias.requires_grad)):
+        return _BiasGelu.apply(x, bias)
+    return bias_gelu_launch(x, bias)
 
 
 def bias_scale_residual(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:

@@ -88,3 +88,37 @@ def model_forward(img: torch.Tensor, sd: dict, heads: int, patch: int, eps: floa
         pre = f"decoder.layers.{i}."
         x = layer_forward(x, {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, heads, eps)
     return x.permute(1, 0, 2).contiguous()
+
+
+def pixel_shuffle(x: torch.Tensor, scale_factor: float = 0.5) -> torch.Tensor:
+    """pretrain_lcvlm.py:546-556 (pinned bit-exact by tests/golden/indexing.npz)."""
+    n, w, h, c = x.shape
+    x = x.reshape(n, w, int(h * scale_factor), int(c / scale_factor)).permute(0, 2, 1, 3)
+    x = x.reshape(n, int(h * scale_factor), int(w * scale_factor), int(c / (scale_factor * scale_factor)))
+    return x.permute(0, 2, 1, 3).contiguous()
+
+
+def projector_mlp(x: torch.Tensor, sd: dict):
+    """Megatron MLP as pretrain_lcvlm.py:391-400 configures it for the projector: no gating, no biases, erf GELU."""
+    inter = gelu(F.linear(x.float(), sd["vision_projection.encoder.linear_fc1.weight"].float()))
+    return F.linear(inter, sd["vision_projection.encoder.linear_fc2.weight"].float()), None
+
+
+def forward_projection(x: torch.Tensor, sd: dict, eps: float = 1e-5) -> torch.Tensor:
+    """pretrain_lcvlm.py:439-451 + multimodal_projector.py:53-80: torch.nn.LayerNorm (default eps) then the MLP."""
+    x = layer_norm(x, sd["pre_proj_layernorm.weight"], sd["pre_proj_layernorm.bias"], eps)
+    out, bias = projector_mlp(x, sd)
+    return out if bias is None else out + bias
+
+
+def vision_model_forward(images: torch.Tensor, sd: dict, heads: int, patch: int, vit_eps: float) -> torch.Tensor:
+    """pretrain_lcvlm.py:453-507 (class token dropped, downsample ratio 0.5, pre-norm projector): images
+    [n, 3, H, W] -> [n, tokens / 4, llm_hidden]."""
+    vit_sd = {k[4:]: v for k, v in sd.items() if k.startswith("vit.")}
+    outs = []
+    for chunk in torch.split(images, 256, dim=0):
+        y = model_forward(chunk, vit_sd, heads, patch, vit_eps)[:, 1:, :]
+        g = int(y.shape[1] ** 0.5)
+        y = pixel_shuffle(y.reshape(y.shape[0], g, g, -1), 0.5)
+        outs.append(forward_projection(y.reshape(y.shape[0], -1, y.shape[-1]), sd))
+    return torch.cat(outs, dim=0)

@@ -395,24 +395,27 @@ def gen_vit():
     def rnd(*shape, scale=1.0):
         return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
 
-    sd = {"conv1.weight": rnd(h, 3, patch, patch, scale=0.05), "conv1.bias": rnd(h, scale=0.1),
-          "class_token": rnd(1, 1, h), "position_embeddings.weight": rnd(seq, h, scale=0.2)}
-    for i in range(n_layers):
-        pre = f"decoder.layers.{i}."
-        sd[pre + "input_layernorm.weight"] = 1 + rnd(h, scale=0.1)
-        sd[pre + "input_layernorm.bias"] = rnd(h, scale=0.1)
-        sd[pre + "self_attention.linear_qkv.weight"] = rnd(3 * h, h, scale=0.15)
-        sd[pre + "self_attention.linear_qkv.bias"] = rnd(3 * h, scale=0.1)
-        sd[pre + "self_attention.linear_proj.weight"] = rnd(h, h, scale=0.15)
-        sd[pre + "self_attention.linear_proj.bias"] = rnd(h, scale=0.1)
-        sd[pre + "pre_mlp_layernorm.weight"] = 1 + rnd(h, scale=0.1)
-        sd[pre + "pre_mlp_layernorm.bias"] = rnd(h, scale=0.1)
-        sd[pre + "mlp.linear_fc1.weight"] = rnd(ffn, h, scale=0.15)
-        sd[pre + "mlp.linear_fc1.bias"] = rnd(ffn, scale=0.1)
-        sd[pre + "mlp.linear_fc2.weight"] = rnd(h, ffn, scale=0.15)
-        sd[pre + "mlp.linear_fc2.bias"] = rnd(h, scale=0.1)
-        sd[pre + "ls1"] = rnd(h, scale=0.5)   # larger than the 0.01 initial value so the branches matter
-        sd[pre + "ls2"] = rnd(h, scale=0.5)
+    def make_sd(seq):
+        sd = {"conv1.weight": rnd(h, 3, patch, patch, scale=0.05), "conv1.bias": rnd(h, scale=0.1),
+              "class_token": rnd(1, 1, h), "position_embeddings.weight": rnd(seq, h, scale=0.2)}
+        for i in range(n_layers):
+            pre = f"decoder.layers.{i}."
+            sd[pre + "input_layernorm.weight"] = 1 + rnd(h, scale=0.1)
+            sd[pre + "input_layernorm.bias"] = rnd(h, scale=0.1)
+            sd[pre + "self_attention.linear_qkv.weight"] = rnd(3 * h, h, scale=0.15)
+            sd[pre + "self_attention.linear_qkv.bias"] = rnd(3 * h, scale=0.1)
+            sd[pre + "self_attention.linear_proj.weight"] = rnd(h, h, scale=0.15)
+            sd[pre + "self_attention.linear_proj.bias"] = rnd(h, scale=0.1)
+            sd[pre + "pre_mlp_layernorm.weight"] = 1 + rnd(h, scale=0.1)
+            sd[pre + "pre_mlp_layernorm.bias"] = rnd(h, scale=0.1)
+            sd[pre + "mlp.linear_fc1.weight"] = rnd(ffn, h, scale=0.15)
+            sd[pre + "mlp.linear_fc1.bias"] = rnd(ffn, scale=0.1)
+            sd[pre + "mlp.linear_fc2.weight"] = rnd(h, ffn, scale=0.15)
+            sd[pre + "mlp.linear_fc2.bias"] = rnd(h, scale=0.1)
+            sd[pre + "ls1"] = rnd(h, scale=0.5)   # larger than the 0.01 initial value so the branches matter
+            sd[pre + "ls2"] = rnd(h, scale=0.5)
+        return sd
+    sd = make_sd(seq)
 
     def layer_ns(i):
         pre = f"decoder.layers.{i}."
@@ -432,20 +435,84 @@ def gen_vit():
     y, _ = layer_fwd(layer_ns(0), x, None)
     out["layer0.out"] = y.numpy()
 
-    conv = torch.nn.Conv2d(3, h, kernel_size=patch, stride=patch, bias=True)
-    conv.weight.data.copy_(sd["conv1.weight"]); conv.bias.data.copy_(sd["conv1.bias"])
-    pos = torch.nn.Embedding(seq, h); pos.weight.data.copy_(sd["position_embeddings.weight"])
+    def vit_self(sd, seq):
+        conv = torch.nn.Conv2d(3, h, kernel_size=patch, stride=patch, bias=True)
+        conv.weight.data.copy_(sd["conv1.weight"]); conv.bias.data.copy_(sd["conv1.bias"])
+        pos = torch.nn.Embedding(seq, h); pos.weight.data.copy_(sd["position_embeddings.weight"])
 
-    def decoder(x, mask):
-        for i in range(n_layers):
-            x, _ = layer_fwd(layer_ns(i), x, mask)
-        return x
-    self = ns(conv1=conv, add_class_token=True, class_token=sd["class_token"], seq_length=seq, position_embeddings=pos,
-              position_ids=torch.arange(seq).expand(1, -1), vision_context_parallel=False, decoder=decoder)
+        def layer_of(i):
+            pre = f"decoder.layers.{i}."
+            p = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+            sub = lambda name: {k[len(name) + 1:]: v for k, v in p.items() if k.startswith(name + ".")}
+            return ns(input_layernorm=lambda x: vit_ref.layer_norm(x, p["input_layernorm.weight"], p["input_layernorm.bias"], eps),
+                      pre_mlp_layernorm=lambda x: vit_ref.layer_norm(x, p["pre_mlp_layernorm.weight"], p["pre_mlp_layernorm.bias"], eps),
+                      self_attention=lambda x, **kw: vit_ref.self_attention(x, sub("self_attention"), heads),
+                      mlp=lambda x: vit_ref.mlp(x, sub("mlp")), ls1=p["ls1"], ls2=p["ls2"])
+
+        def decoder(x, mask):
+            for i in range(n_layers):
+                x, _ = layer_fwd(layer_of(i), x, mask)
+            return x
+        return ns(conv1=conv, add_class_token=True, class_token=sd["class_token"], seq_length=seq, position_embeddings=pos,
+                  position_ids=torch.arange(seq).expand(1, -1), vision_context_parallel=False, decoder=decoder)
+
     img = rnd(n, 3, img_hw, img_hw)
     out["model.img"] = img.numpy()
     with torch.no_grad():
-        out["model.out"] = ivm.InternViTModel.forward(self, img).numpy()
+        out["model.out"] = ivm.InternViTModel.forward(vit_self(sd, seq), img).numpy()
+
+    # ---- the vision model around the tower: MegatronVisionModel.forward -> forward_chunk -> forward_once
+    # (class-token drop, pixel_shuffle 0.5) -> forward_projection -> MultimodalProjector.forward
+    # (pretrain_lcvlm.py:439-556, multimodal_projector.py:53-80), all run from the reference's class bodies.
+    pl = importlib.import_module("lcvlm_modellink.pretrain_lcvlm")
+    mp = importlib.import_module("lcvlm_modellink.core.models.vision.multimodal_projector")
+    pl.mpu = ns(get_context_parallel_world_size=lambda: 1, get_context_parallel_rank=lambda: 0)
+    VM = pl.MegatronVisionModel
+    vm_img_hw, vm_n, llm_h = 56, 3, 192
+    vm_seq = (vm_img_hw // patch) ** 2 + 1
+    vsd = make_sd(vm_seq)
+    vm_sd = {"vit." + k: v for k, v in vsd.items()}
+    vm_sd["pre_proj_layernorm.weight"] = 1 + rnd(4 * h, scale=0.1)
+    vm_sd["pre_proj_layernorm.bias"] = rnd(4 * h, scale=0.1)
+    vm_sd["vision_projection.encoder.linear_fc1.weight"] = rnd(h, 4 * h, scale=0.08)
+    vm_sd["vision_projection.encoder.linear_fc2.weight"] = rnd(llm_h, h, scale=0.15)
+    ln = torch.nn.LayerNorm(4 * h)
+    ln.weight.data.copy_(vm_sd["pre_proj_layernorm.weight"]); ln.bias.data.copy_(vm_sd["pre_proj_layernorm.bias"])
+    vit_ns = vit_self(vsd, vm_seq)
+    proj_ns = ns(encoder=lambda x: vit_ref.projector_mlp(x, vm_sd))
+    vm = ns(vit=lambda images, mask: ivm.InternViTModel.forward(vit_ns, images, mask), add_class_token=True,
+            vision_model_freeze=True, vision_projector_freeze=False, vision_projector_recompute=False,
+            vision_downsample_ratio=0.5, vision_downsample_stride=1, vision_context_parallel=False,
+            pre_proj_layernorm=ln, vision_projection=lambda x: mp.MultimodalProjector.forward(proj_ns, x))
+    vm.pixel_shuffle = lambda x, scale_factor=0.5: VM.pixel_shuffle(vm, x, scale_factor=scale_factor)
+    vm.forward_projection = lambda x: VM.forward_projection(vm, x)
+    vm.forward_once = lambda images, mask: VM.forward_once(vm, images, mask)
+    vm.forward_chunk = lambda images, mask: VM.forward_chunk(vm, images, mask)
+    vimg = rnd(vm_n, 3, vm_img_hw, vm_img_hw)
+    with torch.no_grad():
+        vout = VM.forward(vm, images=vimg)
+    assert vout.shape == (vm_n, (vm_seq - 1) // 4, llm_h), vout.shape
+    out["vm.meta"] = np.array([vm_img_hw, vm_n, llm_h], dtype=np.int64)
+    out["vm.img"] = vimg.numpy()
+    out["vm.out"] = vout.numpy()
+    for k, v in vm_sd.items():
+        out["vmsd." + k] = v.numpy()
+    # gradients of the projector part alone (it trains in every stage): autograd through the reference's
+    # forward_projection on a given tower output
+    px = rnd(2, 4, 4 * h).requires_grad_(True)
+    for prm in ln.parameters():
+        prm.grad = None
+    w1 = vm_sd["vision_projection.encoder.linear_fc1.weight"].clone().requires_grad_(True)
+    w2 = vm_sd["vision_projection.encoder.linear_fc2.weight"].clone().requires_grad_(True)
+    gsd = dict(vm_sd); gsd["vision_projection.encoder.linear_fc1.weight"] = w1; gsd["vision_projection.encoder.linear_fc2.weight"] = w2
+    proj_ns_g = ns(encoder=lambda x: vit_ref.projector_mlp(x, gsd))
+    vm_g = ns(pre_proj_layernorm=ln, vision_projection=lambda x: mp.MultimodalProjector.forward(proj_ns_g, x))
+    po = VM.forward_projection(vm_g, px)
+    pdo = rnd(*po.shape)
+    po.backward(pdo)
+    out["proj.x"], out["proj.dout"], out["proj.out"] = px.detach().numpy(), pdo.numpy(), po.detach().numpy()
+    out["proj.dx"], out["proj.dw1"], out["proj.dw2"] = px.grad.numpy(), w1.grad.numpy(), w2.grad.numpy()
+    out["proj.dln_w"], out["proj.dln_b"] = ln.weight.grad.numpy(), ln.bias.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "vit.npz"), **out)
     print("vit.npz:", len(out), "arrays")
 

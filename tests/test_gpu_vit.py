@@ -139,3 +139,80 @@ def test_rejects_what_it_does_not_build():
     from long_vita_amd import intern_vit as iv
     with pytest.raises(NotImplementedError):
         iv.InternViTModel(iv.InternViTConfig(num_layers=1), vision_context_parallel=True)
+
+
+@pytest.mark.parametrize("rows,h", [(1, 8), (77, 1024), (2051, 4096), (5, 200)])
+def test_layernorm_backward(rows, h):
+    from long_vita_amd import ops
+    x, w, b = _bf(rows, h, seed=31, scale=2.0) + 0.3, 1 + _bf(h, seed=32, scale=0.2), _bf(h, seed=33, scale=0.2)
+    dy = _bf(rows, h, seed=34)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    vit_ref.layer_norm(xr, wr, br, 1e-5).backward(dy.float())
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    ops.layernorm(xg, wg, bg, 1e-5).backward(dy.cuda())
+    _close(xg.grad, xr.grad, 2.0 ** -7)
+    _close(wg.grad, wr.grad, 2.0 ** -7)
+    _close(bg.grad, br.grad, 2.0 ** -7)
+    # parameter gradients are summed in a fixed order: two runs agree bit for bit
+    dx2, dg2, db2 = ops.layernorm_bwd_launch(x.cuda(), dy.cuda(), w.cuda(), 1e-5)
+    dx3, dg3, db3 = ops.layernorm_bwd_launch(x.cuda(), dy.cuda(), w.cuda(), 1e-5)
+    assert torch.equal(dg2, dg3) and torch.equal(db2, db3) and torch.equal(dx2, dx3)
+
+
+def test_layernorm_backward_rejects_wide_rows():
+    from long_vita_amd import ops
+    x = torch.zeros(4, 8192, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ops.LvAttnError):
+        ops.layernorm_bwd_launch(x, x, torch.ones(8192, dtype=torch.bfloat16, device="cuda"), 1e-5)
+
+
+def test_gelu_backward():
+    from long_vita_amd import ops
+    rows, h = 67, 1024
+    x, bias, dy = _bf(rows, h, seed=41, scale=2.0), _bf(h, seed=42), _bf(rows, h, seed=43)
+    for use_bias in (True, False):
+        xr = x.float().requires_grad_(True)
+        br = bias.float().requires_grad_(True)
+        torch.nn.functional.gelu(xr + (br if use_bias else 0.0)).backward(dy.float())
+        xg, bg = x.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+        ops.bias_gelu(xg, bg if use_bias else None).backward(dy.cuda())
+        _close(xg.grad, xr.grad, 2.0 ** -7)
+        if use_bias:
+            _close(bg.grad, br.grad, 2.0 ** -6)
+
+
+def test_vision_model_against_reference_fixture(golden_dir):
+    from long_vita_amd import intern_vit as iv, vision_model as vmod
+    g, _ = _golden(golden_dir)
+    h, heads, ffn, n_layers, patch, _, _ = (int(v) for v in g["meta"])
+    img_hw, n, llm_h = (int(v) for v in g["vm.meta"])
+    cfg = iv.InternViTConfig(hidden_size=h, ffn_hidden_size=ffn, num_attention_heads=heads, num_layers=n_layers, patch_dim=patch,
+                             img_h=img_hw, img_w=img_hw, layernorm_epsilon=float(g["eps"]))
+    m = vmod.MegatronVisionModel(hidden_size=llm_h, vit_config=cfg)
+    m.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("vmsd.")}, strict=True)
+    m = m.to(torch.bfloat16).cuda()
+    out = m(images=torch.from_numpy(g["vm.img"]).to(torch.bfloat16).cuda())
+    assert out.requires_grad          # the projector trains; the tower ran without a graph
+    _close(out, torch.from_numpy(g["vm.out"]))
+
+    # projector gradients against the reference's forward_projection under autograd
+    x = torch.from_numpy(g["proj.x"]).to(torch.bfloat16).cuda().requires_grad_(True)
+    po = m.forward_projection(x)
+    _close(po, torch.from_numpy(g["proj.out"]))
+    po.backward(torch.from_numpy(g["proj.dout"]).to(torch.bfloat16).cuda())
+    enc = m.vision_projection.encoder
+    for got, key in ((x.grad, "proj.dx"), (enc.linear_fc1.weight.grad, "proj.dw1"), (enc.linear_fc2.weight.grad, "proj.dw2"),
+                     (m.pre_proj_layernorm.weight.grad, "proj.dln_w"), (m.pre_proj_layernorm.bias.grad, "proj.dln_b")):
+        _close(got, torch.from_numpy(g[key]))
+
+
+def test_vision_model_chunks_of_256_images():
+    """forward_chunk splits at 256 images; a 258-image batch equals the two passes run separately."""
+    from long_vita_amd import intern_vit as iv, vision_model as vmod
+    cfg = iv.InternViTConfig(hidden_size=128, ffn_hidden_size=256, num_attention_heads=2, num_layers=1, img_h=28, img_w=28)
+    torch.manual_seed(3)
+    m = vmod.MegatronVisionModel(hidden_size=64, vit_config=cfg, vision_projector_freeze=True).to(torch.bfloat16).cuda()
+    img = _bf(258, 3, 28, 28, seed=51).cuda()
+    whole = m(images=img)
+    assert whole.shape == (258, 1, 64) and not whole.requires_grad
+    assert torch.equal(whole[:256], m.forward_once(img[:256])) and torch.equal(whole[256:], m.forward_once(img[256:]))
