@@ -91,6 +91,23 @@ int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* ls
                int64_t o_row_stride, int64_t o_head_stride,
                int64_t lse_stride, float softmax_scale, int causal, void* stream);
 
+/* ---- incremental attention over a KV cache -------------------------------------
+ * Replaces torch_npu.npu_incre_flash_attention as called with --use-kv-cache
+ * (lcvlm_modellink/core/transformer/dot_product_attention.py:428-438: query [b, 1, hq*d], key / value
+ * [b, k_len, hkv*d], layout "BSH", no mask).  q [batch, hq, d], k / v [batch, k_len, hkv, d], out [batch, hq, d]
+ * bf16 with element strides (last dimension contiguous); lse [batch, hq] fp32 (natural log) or NULL.
+ * The key range is cut into n_split pieces (0 = chosen from the device size), each read once by one
+ * workgroup; `workspace` (lvattn_decode_workspace_bytes(...) bytes of device memory, contents undefined
+ * afterwards) holds the pieces' partial results until a second small kernel merges them. */
+int64_t lvattn_decode_workspace_bytes(int batch, int hq, int hkv, int d);
+int lvattn_decode(const void* q, const void* k, const void* v, void* out, float* lse, void* workspace,
+                  int64_t workspace_bytes, int batch, int k_len, int hq, int hkv, int d,
+                  int64_t q_batch_stride, int64_t q_head_stride,
+                  int64_t k_batch_stride, int64_t k_row_stride, int64_t k_head_stride,
+                  int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
+                  int64_t o_batch_stride, int64_t o_head_stride,
+                  float softmax_scale, int n_split, void* stream);
+
 /* ---- attention backward -----------------------------------------------------
  * Replaces the autograd of the calls above (npu_fusion_attention_grad, reached
  * through torch autograd from dot_product_attention.py:352-365 / :314-325) and the

@@ -15,8 +15,9 @@ can point at this module unchanged.  Differences, on purpose:
     args.sparse_mode / shape_order / pre_tockens as a side effect, :329,383,389,406);
   * packed segments + context parallelism raises NotImplementedError instead of
     the reference's latent TypeError (:342-343 passes a keyword :36 does not take);
-  * alibi / pse, sliding window and the kv-cache decode ops are outside this path
-    and raise NotImplementedError.
+  * alibi / pse and sliding window are outside this path and raise NotImplementedError;
+  * the kv-cache prompt op always applies the causal mask aligned to the end of the keys (the
+    reference forwards args.sparse_mode and its stored mask, which describe the same thing).
 """
 from __future__ import annotations
 
@@ -24,7 +25,7 @@ import math
 from functools import wraps
 
 from . import state
-from .fusion_attention import npu_fusion_attention
+from .fusion_attention import npu_fusion_attention, npu_incre_flash_attention, npu_prompt_flash_attention
 from .ring_context_parallel import ringattn_context_parallel
 
 _RING_ALGOS = ("megatron_cp_algo", "hybrid_cp_algo")
@@ -109,7 +110,16 @@ def flash_attention_forward(self, query, key, value, attention_mask, attn_mask_t
     if args.sliding_window is not None and seq_length > args.sliding_window:
         raise NotImplementedError("sliding-window attention is not supported")
     if getattr(args, "use_kv_cache", False):
-        raise NotImplementedError("kv-cache prompt/incremental attention is not supported")
+        # :428-452: 's b h -> b s h' views of the cache, one new token -> incremental op, else the prompt op
+        q, k, v = (x.reshape(x.shape[0], x.shape[1], -1).transpose(0, 1) for x in (query, key, value))
+        if q.shape[1] == 1 and q.shape[1] != k.shape[1]:
+            output = npu_incre_flash_attention(q, k, v, num_heads=n_head, input_layout="BSH", pse_shift=None,
+                                               padding_mask=None, scale_value=scale)
+        else:
+            output = npu_prompt_flash_attention(q, k, v, num_heads=n_head, input_layout="BSH", pse_shift=None,
+                                                sparse_mode=2, padding_mask=None, atten_mask=True, scale_value=scale,
+                                                pre_tokens=args.pre_tockens, next_tokens=0)
+        return output.transpose(0, 1)
     causal_mask = True  # generic path: the causal template mask (:384) / get_attention_mask()
     if args.shape_order == "TND":
         # '(s b)' flattening (:382): sequence-major, segments from actual_seq_len

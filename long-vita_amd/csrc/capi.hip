@@ -179,6 +179,51 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
 }
 
 // ---------------------------------------------------------------------------
+// incremental attention over a KV cache
+// ---------------------------------------------------------------------------
+extern "C" int64_t lvattn_decode_workspace_bytes(int batch, int hq, int hkv, int d) {
+    if (batch <= 0 || hq <= 0 || hkv <= 0 || d <= 0 || hq % hkv) return 0;
+    const int64_t group = hq / hkv;
+    return (int64_t)batch * hkv * LV_DECODE_MAX_SPLITS * group * (d + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int lvattn_decode(const void* q, const void* k, const void* v, void* out, float* lse, void* workspace,
+                             int64_t workspace_bytes, int batch, int k_len, int hq, int hkv, int d,
+                             int64_t q_bs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                             int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_hs,
+                             float scale, int n_split, void* stream) {
+    if (int e = check_common(q, k, v, hq, hkv, d, q_bs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
+    if (!out || !workspace) return fail(LV_EINVAL, "lvattn_decode: null out/workspace pointer");
+    if (batch <= 0 || k_len <= 0) return fail(LV_EINVAL, "lvattn_decode: batch=%d k_len=%d", batch, k_len);
+    if (hq / hkv > 32) return fail(LV_EINVAL, "lvattn_decode: %d query heads per KV head (at most 32)", hq / hkv);
+    if ((k_bs | v_bs) & 7) return fail(LV_EINVAL, "lvattn_decode: batch strides must be multiples of 8 elements");
+    if ((uintptr_t)workspace & 15) return fail(LV_EINVAL, "lvattn_decode: workspace must be 16-byte aligned");
+    // the tile loads address a split's rows with 32-bit byte offsets
+    if ((int64_t)LV_DECODE_TILE * (k_rs > v_rs ? k_rs : v_rs) * 2 > 0x7fffffffLL) return fail(LV_EINVAL, "lvattn_decode: row stride too large");
+    const int max_split = (k_len + LV_DECODE_TILE - 1) / LV_DECODE_TILE;
+    if (n_split <= 0) n_split = (512 + batch * hkv - 1) / (batch * hkv);   // two workgroups per CU
+    if (n_split > max_split) n_split = max_split;
+    if (n_split > LV_DECODE_MAX_SPLITS) n_split = LV_DECODE_MAX_SPLITS;
+    int chunk = (k_len + n_split - 1) / n_split;
+    chunk = (chunk + LV_DECODE_TILE - 1) / LV_DECODE_TILE * LV_DECODE_TILE;
+    n_split = (k_len + chunk - 1) / chunk;
+    const int group = hq / hkv;
+    const int64_t need = (int64_t)batch * hkv * n_split * group * (d + 1) * (int64_t)sizeof(float);
+    if (workspace_bytes < need) return fail(LV_EINVAL, "lvattn_decode: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+    if ((int64_t)batch * hkv * n_split > 0x7fffffffLL) return fail(LV_EINVAL, "lvattn_decode: grid too large");
+    DecodeParams p;
+    p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.o = (__bf16*)out; p.lse = lse;
+    p.part_o = (float*)workspace;
+    p.part_lse = p.part_o + (int64_t)batch * hkv * n_split * group * d;
+    p.batch = batch; p.hq = hq; p.hkv = hkv; p.group = group; p.k_len = k_len; p.chunk = chunk; p.n_split = n_split;
+    p.q_bs = q_bs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs;
+    p.o_bs = o_bs; p.o_hs = o_hs;
+    p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+    if (lv_launch_decode(p, d, (hipStream_t)stream)) return fail(LV_ELAUNCH, "lvattn_decode: launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return LV_OK;
+}
+
+// ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
 extern "C" int lvattn_bwd_delta(const void* out, const void* dout, float* delta, int rows, int hq, int d,

@@ -17,6 +17,23 @@ struct FwdParams {
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
 
+// Incremental attention over a KV cache: q [batch, hq, d], k/v [batch, k_len, hkv, d], out [batch, hq, d].
+#define LV_DECODE_MAX_SPLITS 256
+#define LV_DECODE_TILE 128
+struct DecodeParams {
+    const __bf16* q;
+    const __bf16* k;
+    const __bf16* v;
+    __bf16* o;
+    float* lse;        // [batch, hq] or null
+    float* part_o;     // [batch*hkv][n_split][group][d]
+    float* part_lse;   // [batch*hkv][n_split][group]
+    int batch, hq, hkv, group, k_len, chunk, n_split;
+    int64_t q_bs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_hs;
+    float scale, scale_log2e;
+};
+int lv_launch_decode(const DecodeParams& p, int d, hipStream_t stream);
+
 #define LV_BWD_BLOCK_N_INTERNAL 128
 
 struct BwdParams {

@@ -7,6 +7,9 @@ actual_seq_qlen/kvlen) and :454-467 (generic SBH / BNSD / TND).  This function t
 the same arguments and returns a tuple whose element 0 is the attention output in
 the input layout; elements 1 and 2 are (softmax_max, softmax_sum) in the
 decomposition max = log-sum-exp, sum = 1 (lse = max + ln(sum) as in the NPU op).
+
+``npu_incre_flash_attention`` / ``npu_prompt_flash_attention`` stand in for the two ops of the
+``--use-kv-cache`` branch (:428-451): one new token against the cache, and the prompt pass.
 """
 from __future__ import annotations
 
@@ -99,3 +102,52 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
         return out, lse, torch.ones_like(lse)
 
     raise ValueError(f"unknown input_layout {input_layout!r}")
+
+
+def _kv_heads(query, key, num_heads, num_key_value_heads):
+    d = query.shape[-1] // num_heads
+    hkv = num_key_value_heads or key.shape[-1] // d
+    if hkv * d != key.shape[-1] or num_heads % hkv:
+        raise ValueError(f"key width {key.shape[-1]} does not hold {hkv} heads of {d}")
+    return d, hkv
+
+
+def npu_incre_flash_attention(query, key, value, num_heads=1, input_layout="BSH", pse_shift=None, padding_mask=None,
+                              atten_mask=None, scale_value=1.0, num_key_value_heads=0, actual_seq_lengths=None):
+    """query [b, 1, hq*d], key / value [b, k_len, hkv*d] (any strides: the 'b s h' views the reference makes of its
+    [s, b, h] cache are taken as they are) -> [b, 1, hq*d]; every cached key is visible (dot_product_attention.py:430-438)."""
+    if input_layout != "BSH":
+        raise NotImplementedError(f"input_layout {input_layout!r}: the reference calls this op with BSH only")
+    if pse_shift is not None or padding_mask is not None or atten_mask is not None or actual_seq_lengths is not None:
+        raise NotImplementedError("pse_shift / padding_mask / atten_mask / actual_seq_lengths are not supported")
+    b, sq, hd = query.shape
+    if sq != 1:
+        raise ValueError("npu_incre_flash_attention takes one new token per sequence")
+    d, hkv = _kv_heads(query, key, num_heads, num_key_value_heads)
+    out = ops.decode_attention(query.reshape(b, num_heads, d), key.unflatten(2, (hkv, d)), value.unflatten(2, (hkv, d)),
+                               scale_value)
+    return out.reshape(b, 1, hd)
+
+
+def npu_prompt_flash_attention(query, key, value, num_heads=1, input_layout="BSH", pse_shift=None, padding_mask=None,
+                               atten_mask=None, scale_value=1.0, pre_tokens=2147483647, next_tokens=0, sparse_mode=0,
+                               num_key_value_heads=0, actual_seq_lengths=None):
+    """Prompt pass of the kv-cache branch (dot_product_attention.py:440-451): query [b, sq, hq*d], key / value
+    [b, sk, hkv*d].  With a mask the attention is causal, the query block aligned to the END of the keys (the new
+    tokens are the last sq positions of the cache); without one it is full."""
+    if input_layout != "BSH":
+        raise NotImplementedError(f"input_layout {input_layout!r}: the reference calls this op with BSH only")
+    if pse_shift is not None or padding_mask is not None or actual_seq_lengths is not None:
+        raise NotImplementedError("pse_shift / padding_mask / actual_seq_lengths are not supported")
+    causal = _is_causal(atten_mask, sparse_mode if atten_mask is not None else 0, pre_tokens, next_tokens)
+    b, sq, hd = query.shape
+    sk = key.shape[1]
+    d, hkv = _kv_heads(query, key, num_heads, num_key_value_heads)
+    if sk < sq:
+        raise ValueError("fewer keys than queries")
+    outs = []
+    for i in range(b):      # one rectangle per sequence; the views keep the caller's strides
+        q3, k3, v3 = query[i].unflatten(1, (num_heads, d)), key[i].unflatten(1, (hkv, d)), value[i].unflatten(1, (hkv, d))
+        desc = ops.rect_blocks_on_device(0, sq, 0, sk, causal, sk - sq, False, query.device)
+        outs.append(ops.attn_fwd_launch(q3, k3, v3, desc, scale_value, causal)[0].reshape(sq, hd))
+    return torch.stack(outs)

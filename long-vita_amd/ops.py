@@ -142,6 +142,28 @@ def attn_fwd_launch(q, k, v, desc: torch.Tensor, scale: float, causal: bool, out
     return out, lse
 
 
+def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, n_split: int = 0, return_lse: bool = False):
+    """One new token per sequence against a KV cache: q [b, hq, d], k / v [b, k_len, hkv, d] bf16 (any batch / row /
+    head strides, last dimension contiguous) -> out [b, hq, d] (and lse [b, hq] fp32)."""
+    _require_gpu(q, k, v)
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+        raise LvAttnError("q, k, v must be bfloat16")
+    if q.dim() != 3 or k.dim() != 4 or v.shape != k.shape or k.shape[0] != q.shape[0] or k.shape[3] != q.shape[2]:
+        raise LvAttnError("decode_attention expects q [b, hq, d] and k, v [b, k_len, hkv, d]")
+    q, k, v = _last_contig(q), _last_contig(k), _last_contig(v)
+    b, hq, d = q.shape
+    _, k_len, hkv, _ = k.shape
+    out = torch.empty((b, hq, d), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((b, hq), dtype=torch.float32, device=q.device) if return_lse else None
+    nbytes = _lib.lib().lvattn_decode_workspace_bytes(b, hq, hkv, d)
+    ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=q.device)
+    check(_lib.lib().lvattn_decode(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(ws), nbytes, b, k_len, hq, hkv, d,
+                                   q.stride(0), q.stride(1), k.stride(0), k.stride(1), k.stride(2),
+                                   v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1),
+                                   float(scale), int(n_split), _stream()), "lvattn_decode")
+    return (out, lse) if return_lse else out
+
+
 def attn_bwd_launch(q, k, v, out, dout, lse, desc_q: torch.Tensor, desc_k: torch.Tensor, scale: float, causal: bool,
                     dq=None, dk=None, dv=None, delta=None, accum_f32: bool = False):
     """Backward of ``attn_fwd_launch``.  ``desc_q`` are the forward's query-block descriptors

@@ -1,0 +1,119 @@
+"""Incremental attention over a KV cache (the --use-kv-cache branch of the reference's flash path) against the
+float64 oracle.  The NPU ops it stands in for are not in the reference tree: parity unpinned beyond the
+softmax-attention definition the eager path pins.  Tolerances: output 2e-2 of the largest magnitude, LSE 1e-3."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention_ref as A
+
+pytestmark = pytest.mark.gpu
+REL_TOL, LSE_TOL = 2e-2, 1e-3
+
+
+def _rnd(*shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _check(out, lse, q, k, v, scale):
+    b = q.shape[0]
+    for i in range(b):
+        ref_o, ref_l = A.block_attention(q[i][None], k[i], v[i], scale, None)     # q row [1, hq, d]
+        got = out[i].float().cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref_o[0]).max() <= REL_TOL * np.abs(ref_o).max()
+        if lse is not None:
+            assert np.abs(lse[i].cpu().numpy() - ref_l[:, 0]).max() <= LSE_TOL
+
+
+CASES = [
+    # b, hq, hkv, d, k_len, n_split
+    (1, 40, 8, 128, 1, 0),
+    (1, 40, 8, 128, 5, 0),
+    (1, 40, 8, 128, 127, 0),
+    (1, 40, 8, 128, 128, 0),
+    (1, 40, 8, 128, 129, 0),
+    (1, 40, 8, 128, 1000, 3),
+    (1, 40, 8, 128, 40000, 0),
+    (2, 40, 8, 128, 3001, 7),
+    (3, 16, 16, 64, 777, 0),
+    (1, 32, 1, 128, 2500, 0),      # a full 32-row group
+    (2, 6, 2, 64, 4096, 1),        # one split walks every tile
+]
+
+
+@pytest.mark.parametrize("b,hq,hkv,d,k_len,n_split", CASES)
+def test_decode_matches_oracle(b, hq, hkv, d, k_len, n_split):
+    from long_vita_amd import ops
+    q, k, v = _rnd(b, hq, d, seed=1), _rnd(b, k_len, hkv, d, seed=2), _rnd(b, k_len, hkv, d, seed=3)
+    scale = 1.0 / math.sqrt(d)
+    out, lse = ops.decode_attention(q.cuda(), k.cuda(), v.cuda(), scale, n_split=n_split, return_lse=True)
+    _check(out, lse, q, k, v, scale)
+
+
+def test_decode_peaked_scores_and_split_merge():
+    """A few keys dominate, placed in different splits and tiles: exercises the running-maximum rescale inside a wave,
+    the merge of the four waves and the merge of the splits."""
+    from long_vita_amd import ops
+    b, hq, hkv, d, k_len = 1, 10, 2, 128, 6000
+    q, k, v = _rnd(b, hq, d, seed=4), _rnd(b, k_len, hkv, d, seed=5, scale=0.3), _rnd(b, k_len, hkv, d, seed=6)
+    for pos, gain in ((17, 2.0), (2900, 3.0), (5999, 4.0)):
+        k[0, pos, 0] = (q[0, 0].float() * gain).to(torch.bfloat16)
+        k[0, pos, 1] = (q[0, 7].float() * gain).to(torch.bfloat16)
+    scale = 1.0 / math.sqrt(d)
+    for n_split in (1, 4, 0):
+        out, lse = ops.decode_attention(q.cuda(), k.cuda(), v.cuda(), scale, n_split=n_split, return_lse=True)
+        _check(out, lse, q, k, v, scale)
+
+
+def test_decode_on_views_of_a_sequence_major_cache():
+    """The reference keeps the cache as [s, b, heads, d] and hands 'b s h' views to the op."""
+    from long_vita_amd import ops
+    s_max, b, hq, hkv, d, k_len = 700, 2, 10, 2, 128, 515
+    cache_k, cache_v = _rnd(s_max, b, hkv, d, seed=7).cuda(), _rnd(s_max, b, hkv, d, seed=8).cuda()
+    q = _rnd(b, hq, d, seed=9)
+    kview, vview = cache_k[:k_len].transpose(0, 1), cache_v[:k_len].transpose(0, 1)
+    assert not kview.is_contiguous()
+    out = ops.decode_attention(q.cuda(), kview, vview, 0.1)
+    _check(out, None, q, kview.cpu(), vview.cpu(), 0.1)
+
+
+def test_decode_rejects_bad_arguments():
+    from long_vita_amd import ops
+    q, k = _rnd(1, 66, 128, seed=1).cuda(), _rnd(1, 64, 2, 128, seed=2).cuda()
+    with pytest.raises(ops.LvAttnError):
+        ops.decode_attention(q, k, k, 0.1)                 # 33 query heads per KV head
+    with pytest.raises(ops.LvAttnError):
+        ops.decode_attention(q.cpu(), k.cpu(), k.cpu(), 0.1)
+    with pytest.raises(ops.LvAttnError):
+        ops.decode_attention(q[:, :4], k[:, :0], k[:, :0], 0.1)   # empty cache
+
+
+def test_kv_cache_branch_of_flash_attention_forward():
+    """Prompt pass + token-by-token incremental passes through flash_attention_forward (--use-kv-cache) give the rows
+    of one causal attention over the whole sequence."""
+    from long_vita_amd import core_attention, state
+    S, P, b, hq, hkv, d = 300, 291, 2, 10, 2, 128
+    q, k, v = _rnd(S, b, hq, d, seed=11), _rnd(S, b, hkv, d, seed=12), _rnd(S, b, hkv, d, seed=13)
+    scale = 1.0 / math.sqrt(d)
+    state.set_args(state.make_args(use_kv_cache=True))
+    try:
+        self = types.SimpleNamespace(hidden_size_per_attention_head=d, scale_mask_softmax=types.SimpleNamespace(scale=None),
+                                     softmax_scale=scale, norm_factor=math.sqrt(d), alibi=None,
+                                     attention_dropout=types.SimpleNamespace(p=0.0))
+        qg, kg, vg = q.cuda(), k.cuda(), v.cuda()
+        rows = [core_attention.flash_attention_forward(self, qg[:P], kg[:P], vg[:P], None, None, None)]
+        assert rows[0].shape == (P, b, hq * d)
+        # a second multi-token chunk against the longer cache (causal, aligned to the end of the keys)
+        rows.append(core_attention.flash_attention_forward(self, qg[P:P + 4], kg[:P + 4], vg[:P + 4], None, None, None))
+        for t in range(P + 4, S):
+            rows.append(core_attention.flash_attention_forward(self, qg[t:t + 1], kg[:t + 1], vg[:t + 1], None, None, None))
+        got = torch.cat(rows, dim=0).float().cpu().numpy().reshape(S, b, hq, d)
+    finally:
+        state.set_args(None)
+    for i in range(b):
+        ref, _ = A.varlen_attention(q[:, i], k[:, i], v[:, i], [0, S], scale, True)
+        assert np.abs(got[:, i] - ref).max() <= REL_TOL * np.abs(ref).max()
