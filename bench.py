@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line: metric tokens/s for the whole job, plus
                timed on the host cores on a bounded row sample, extrapolated.
 
 Other workloads (``cfg3_fwd_bwd``: 128K packed tokens forward+backward; ``rope_qk``: rotary embedding of Q and K;
-``cfg2_vit``: InternViT-300M attention on 64 frames; ``vit_tower``: the whole InternViT-300M encoder forward on 64 tiles) are for profiling; the
+``cfg2_vit``: InternViT-300M attention on 64 frames; ``decode``: one token against a 1M-token KV cache; ``vit_tower``: the whole InternViT-300M encoder forward on 64 tiles) are for profiling; the
 judged line is the default one.
 """
 from __future__ import annotations
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "vit_tower", "rope_qk"])
+    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "vit_tower", "rope_qk", "decode"])
     ap.add_argument("--seq", type=int, default=0, help="override the sequence length (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -237,6 +237,24 @@ def main():
         flops_per_step = flops_per_gpu_step = 0.0
         config = {"workload": "rope_qk: rotary embedding of Q [S,40,128] and K [S,8,128], in place", "seq_len": S}
         scaling = "weak"
+    elif wl == "decode":  # one new token against a 1M-token KV cache, one layer (bandwidth-bound: the cache is read once)
+        S = args.seq or 1048576
+        q, kc, vc = rnd(1, HQ, D), rnd(1, S, HKV, D), rnd(1, S, HKV, D)
+        scale = 1.0 / math.sqrt(D)
+
+        def step():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(16):
+                ops.decode_attention(q, kc, vc, scale)
+            e1.record()
+            return e0, e1
+        tokens_per_step = 16
+        hbm_bytes_per_step = 16 * 2.0 * S * HKV * D * 2
+        flops_per_step = flops_per_gpu_step = 0.0
+        config = {"workload": "decode: 16 incremental attention calls, 1 query token x KV cache [1, S, 8, 128] (K and V read once each)",
+                  "seq_len": S, "q_heads": HQ, "kv_heads": HKV, "head_dim": D}
+        scaling = "weak"
     elif wl == "vit_tower":  # the whole frozen InternViT-300M encoder on 64 tiles of 448 x 448 (random weights)
         from long_vita_amd import intern_vit as iv
         B = 64
@@ -308,7 +326,7 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": "algorithmic FLOPs per GPU per step / mean device time per step (HIP events on the launch stream)"},
         }
-        if wl == "rope_qk":
+        if wl in ("rope_qk", "decode"):
             gbs = hbm_bytes_per_step / mean_kernel_s / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                "traffic": None, "note": "algorithmic bytes per step / mean device time per step"}
