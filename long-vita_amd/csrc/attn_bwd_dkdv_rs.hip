@@ -17,6 +17,7 @@
 // The sweep walks the query slices from the last one down (see attn_bwd.hip).
 #include "internal.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) char lds_char;
 
@@ -46,26 +47,26 @@ __device__ __forceinline__ void rs_dma4(const float* g, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
 
-template <int D, bool CAUSAL, bool ACCUM_F32>
+template <int D, bool CAUSAL, bool ACCUM_F32, int NSL>
 __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     constexpr int NW = 8;
-    constexpr int BQ = 32;             // query rows per slice
+    constexpr int BQ = 32;             // query rows per unit (one 32-row slice of one head)
     constexpr int KS = D / 16;
     constexpr int MT = D / 32;
     constexpr int ROWB = D * 2;
     constexpr int CPR = D / 8;
-    constexpr int QTILE = BQ * ROWB;   // bytes of a Q (or dO) slice
-    constexpr int NBUF = 5;            // ring slots
-    constexpr int AHEAD = 3;           // staging distance in slices
-    constexpr int SLOTB = 2 * QTILE + NW * 256;  // [Q slice][dO slice][8 x (32 lse, 32 delta) f32: one copy per wave]
+    constexpr int QTILE = BQ * ROWB;   // bytes of a unit's Q (or dO) rows
+    constexpr int NBUF = 4 * NSL;      // ring slots: units of iterations it-1 .. it+2
+    constexpr int AHEAD = 2 * NSL;     // staging distance in units
+    constexpr int SLOTB = 2 * QTILE + 256;        // [Q rows][dO rows][32 lse, 32 delta f32]
     constexpr int RPP = 64 / CPR;                 // rows per 1-KiB piece
-    constexpr int PPW = (2 * QTILE / 1024) / NW;  // pieces per wave per slice: 2 (d=128) or 1 (d=64)
-    constexpr int LPI = PPW + 1;                  // loads per wave per slice
-    constexpr int PBUF = 4 * 2048;                // P of one slice: 4 wave pairs x (64 lanes x 32 bytes)
+    constexpr int PPW = (2 * QTILE / 1024) / NW;  // pieces per wave per unit: 2 (d=128) or 1 (d=64)
+    constexpr int LPI = PPW + 1;                  // loads per wave per unit
+    constexpr int PBUF = 4 * 2048;                // P of one unit: 4 wave pairs x (2 halves x 64 lanes x 16 bytes)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* const lds0 = (lds_char*)smem;
-    lds_char* const ldsP = lds0 + NBUF * SLOTB;   // [2][PBUF]
+    lds_char* const ldsP = lds0 + NBUF * SLOTB;   // [NSL][PBUF]
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds0);
 
     const int tid = threadIdx.x;
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     const int q_row0 = dsc.b_row0, q_len = dsc.b_len;
     const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
     const int nslice = (q_len + BQ - 1) / BQ;
-    const int niter = nslice * p.group;
+    const int nunits = nslice * p.group;
+    const int niter = (nunits + NSL - 1) / NSL;   // the last iteration may hold dead units (P forced to 0)
 
     // ---- this wave's B operand: K fragments (V-wave) or V fragments (K-wave) of key 32*pair + r
     const int kbase_w = 32 * pair;
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bfr[ks]));
 
-    // ---- staging of a (slice, head): waves 0-3 bring the Q rows, waves 4-7 the dO rows; piece j of
-    // wave w is rows RPP*(PPW*(w&3) + j) .. +RPP-1.  The swizzle of the LDS image goes on the source.
+    // ---- staging of a unit: waves 0-3 bring the Q rows, waves 4-7 the dO rows; piece j of wave w is
+    // rows RPP*(PPW*(w&3) + j) .. +RPP-1.  The swizzle of the LDS image goes on the source.
     const int64_t x_rs = is_k ? p.do_rs : p.q_rs;
     const int64_t x_hs = is_k ? p.do_hs : p.q_hs;
     const __bf16* const x_base = (is_k ? p.dout : p.q) + (int64_t)q_row0 * x_rs;
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
     const int64_t x_step_head = x_hs * 2;
     const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
-    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31
+    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31.  Every wave
+    // writes the same 256 bytes of the slot (one copy, identical data), which keeps the load count per
+    // wave uniform.
     const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
     const int64_t c_step_head = p.lse_stride;
     const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
@@ -134,10 +138,10 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
         const uint32_t dst = ld_slot + (is_k ? QTILE : 0) + PPW * pair * 1024;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) rs_dma16(rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
-        rs_dma4(ld_c + (partial ? c_part : 0), ld_slot + 2 * QTILE + w * 256);  // every wave keeps its own copy
-        // past the last slice the stream stays where it is: the loop's unconditional requests re-fetch
-        // that slice into a slot nobody reads any more
-        const bool adv = (++ld_n < niter);
+        rs_dma4(ld_c + (partial ? c_part : 0), ld_slot + 2 * QTILE);
+        // past the last unit the stream stays where it is: the loop's unconditional requests re-fetch that
+        // unit (into slots only dead units read)
+        const bool adv = (++ld_n < nunits);
         const bool wrap = (ld_hg + 1 == p.group);
         const int64_t xs = wrap ? x_step_slice : x_step_head, cs = wrap ? c_step_slice : c_step_head;
         ld_x += adv ? xs : 0;
@@ -161,9 +165,9 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh)
             t_ptr[mt][jh] = lds0 + col_op + lds_off_rs<D>(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
-    // this wave's copy of the row constants: lse (V-wave) or delta (K-wave) of rows 8g+4h .. +3
-    lds_char* const ld_ptr = lds0 + 2 * QTILE + w * 256 + 16 * h + (is_k ? 128 : 0);
-    lds_char* const p_ptr = ldsP + pair * 2048 + lane * 32;                // this lane's P (two 16-byte halves)
+    // row constants: lse (V-wave) or delta (K-wave) of rows 8g+4h .. +3
+    lds_char* const ld_ptr = lds0 + 2 * QTILE + 16 * h + (is_k ? 128 : 0);
+    lds_char* const p_ptr = ldsP + pair * 2048 + lane * 16;   // this lane's P: halves at +0 and +1024
 
     f32x16 acc[MT];   // dV^T (V-wave) or dK^T (K-wave)
 #pragma unroll
@@ -173,17 +177,19 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     const float c = p.scale_log2e;
 
     // Both roles run the SAME loop, with role-dependent operand addresses, the K-waves one barrier
-    // behind the V-waves:
-    //   VALU(s) : Y_s = f(X_s)     V-wave: P_s = exp2(c S_s - lse2), masked, also written to LDS for the partner
-    //                              K-wave: dS_s = P_s (dP_s - delta), P_s read back from LDS
-    //   MFMA(s) : X_{s+1} = A_rows(slice s+1) B^T   (V: S = Q K^T        K: dP = dO V^T)        8 MFMAs
-    //             acc    += A_cols(slice s)^T Y_s    (V: dV^T += dO^T P   K: dK^T += Q^T dS)     8 MFMAs
+    // behind the V-waves.  An iteration handles NSL units u:
+    //   VALU(it) : Y_u = f(X_u)    V-wave: P = exp2(c S - lse2), masked, also written to LDS for the partner
+    //                              K-wave: dS = P (dP - delta), P read back from LDS
+    //   MFMA(it) : X_u' = A_rows(unit of it+1) B^T   (V: S = Q K^T        K: dP = dO V^T)        8 MFMAs per unit
+    //              acc += A_cols(unit of it)^T Y_u    (V: dV^T += dO^T P   K: dK^T += Q^T dS)     8 MFMAs per unit
     // so on every SIMD one wave is in its matrix phase while its partner is in its vector phase, and the
     // accumulators never cross a control-flow merge.  The LDS fragments of MFMA group g+1 are read while
-    // group g runs.
-    constexpr int NG = 4;               // MFMA groups per matrix phase
+    // group g runs.  More units per iteration = longer phases for the same two barriers.
+    constexpr int NG = 4;               // MFMA groups per unit
+    constexpr int NGT = NG * NSL;       // groups per matrix phase
     constexpr int XPG = KS / NG;        // X-chain steps per group: 2 or 1
     constexpr int APG = (2 * MT) / NG;  // accumulator products per group: 2 or 1
+    static_assert(APG == XPG, "one accumulator product per X-chain step");
     bf16x8 rfr[2][XPG], cfr[2][APG];
     auto load_group = [&](int g, int set, int sb_x, int sb_a) __attribute__((always_inline)) {
 #pragma unroll
@@ -203,88 +209,103 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) issue_dma();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        f32x16 x;
+        f32x16 x[NSL];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = 0.f;
+        for (int u = 0; u < NSL; ++u) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks]));
-            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) x[u][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks] + u * SLOTB));
+                x[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x[u], 0, 0, 0);
+            }
         }
-        // row constants of slice s, read one matrix phase ahead: -lse * log2(e) (V-wave) or -delta (K-wave)
+        // row constants of a unit, read one matrix phase ahead: -lse * log2(e) (V-wave) or -delta (K-wave)
         // of rows 8g+4h .. +3, so that the vector phase starts on registers, not on an LDS round trip
         const float cmul = is_k ? -1.f : -1.4426950408889634f;
-        f32x4 cst[4];
-        auto load_consts = [&](int sbx) __attribute__((always_inline)) {
+        f32x4 cst[NSL][4];
+        auto load_consts = [&](int u, int sbx) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 t4 = *(LDS_PTR(f32x4, ld_ptr + sbx + 32 * g));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) cst[g][e] = t4[e] * cmul;
+                for (int e = 0; e < 4; ++e) cst[u][g][e] = t4[e] * cmul;
             }
         };
-        load_consts(0);
-        bf16x8 y[2];
-        int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of slice s
-        int sb = 0;                       // ring byte offset of slice s
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) load_consts(u, u * SLOTB);
+        bf16x8 y[NSL][2];
+        int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of the next unit
+        int c_n = 0;                      // units consumed so far
+        int sb = 0;                       // ring byte offset of this iteration's first unit
         if (is_k) asm volatile("s_barrier" ::: "memory");
-        for (int s = 0; s < niter; ++s) {
-            const int i0 = c_sl * BQ;  // first query row of slice s, relative to q_row0
-            if (++c_hg == p.group) { c_hg = 0; --c_sl; }
-            const int sb_next = (sb + SLOTB == NBUF * SLOTB) ? 0 : sb + SLOTB;
-            // ================= VALU(s) =================
-            if (!is_k) {
-                const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
-                float pv[16];
+        for (int it = 0; it < niter; ++it) {
+            const int sb_next = (sb + NSL * SLOTB == NBUF * SLOTB) ? 0 : sb + NSL * SLOTB;
+            // ================= VALU(it) =================
 #pragma unroll
-                for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(__builtin_fmaf(x[i], c, cst[i >> 2][i & 3]));
-                if (need_mask) {
+            for (int u = 0; u < NSL; ++u) {
+                const int i0 = c_sl * BQ;  // first query row of the unit, relative to q_row0
+                const bool dead_unit = (NSL > 1) && (c_n >= nunits);
+                ++c_n;
+                if (++c_hg == p.group) { c_hg = 0; --c_sl; }
+                if (!is_k) {
+                    const bool need_mask = dead_unit || (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+                    float pv[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
-                        pv[i] = dead ? 0.f : pv[i];
-                        asm volatile("" : "+v"(pv[i]));  // keeps this a branch
+                    for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(__builtin_fmaf(x[u][i], c, cst[u][i >> 2][i & 3]));
+                    if (need_mask) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows) | dead_unit;
+                            pv[i] = dead ? 0.f : pv[i];
+                            asm volatile("" : "+v"(pv[i]));  // keeps this a branch
+                        }
                     }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) y[u][i >> 3][i & 7] = (__bf16)pv[i];
+                    *(LDS_PTR(bf16x8, p_ptr + u * PBUF)) = y[u][0];
+                    *(LDS_PTR(bf16x8, p_ptr + u * PBUF + 1024)) = y[u][1];
+                } else {
+                    bf16x8 pf[2];
+                    pf[0] = *(LDS_PTR(bf16x8, p_ptr + u * PBUF));
+                    pf[1] = *(LDS_PTR(bf16x8, p_ptr + u * PBUF + 1024));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        y[u][i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * (x[u][i] + cst[u][i >> 2][i & 3]));  // (bf16 -> f32 is exact)
                 }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) y[i >> 3][i & 7] = (__bf16)pv[i];
-                *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF)) = y[0];
-                *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF + 16)) = y[1];
-            } else {
-                bf16x8 pf[2];
-                pf[0] = *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF));
-                pf[1] = *(LDS_PTR(bf16x8, p_ptr + (s & 1) * PBUF + 16));
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    y[i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * (x[i] + cst[i >> 2][i & 3]));  // (bf16 -> f32 is exact)
+                asm volatile("" : "+v"(y[u][0]), "+v"(y[u][1]));  // Y is formed here, not next to its first use
             }
-            asm volatile("" : "+v"(y[0]), "+v"(y[1]));  // Y is formed here, not next to its first use
-            issue_dma();   // slice s+3; its slot held slice s-2, whose last reader finished two barriers ago
+            // units of iteration it+2; their slots held iteration it-2, whose last reader finished two barriers ago
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) issue_dma();
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPI) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSL * LPI) : "memory");
             __builtin_amdgcn_sched_barrier(0);
 
-            // ================= MFMA(s): X_{s+1} and acc += A_cols(s)^T Y_s =================
+            // ================= MFMA(it): X of the next iteration's units and acc += A_cols^T Y =================
             __builtin_amdgcn_s_setprio(LV_RS_PRIO_M);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = 0.f;
+            for (int u = 0; u < NSL; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[u][i] = 0.f;
             load_group(0, 0, sb_next, sb);
             __builtin_amdgcn_sched_group_barrier(0x100, XPG + 2 * APG, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int set = g & 1;
-                if (g + 1 < NG) load_group(g + 1, set ^ 1, sb_next, sb);
+            for (int gg = 0; gg < NGT; ++gg) {
+                const int set = gg & 1;
+                const int u = gg / NG, g = gg % NG;
+                if (gg + 1 < NGT) {
+                    const int un = (gg + 1) / NG;
+                    load_group((gg + 1) % NG, set ^ 1, sb_next + un * SLOTB, sb + un * SLOTB);
+                }
 #pragma unroll
                 for (int i = 0; i < XPG; ++i) {
-                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfr[set][i], bfr[XPG * g + i], x, 0, 0, 0);
-                    if (i < APG) {
-                        const int j = APG * g + i;
-                        acc[j % MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfr[set][i], y[j / MT], acc[j % MT], 0, 0, 0);
-                    }
+                    x[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfr[set][i], bfr[XPG * g + i], x[u], 0, 0, 0);
+                    const int j = APG * g + i;
+                    acc[j % MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfr[set][i], y[u][j / MT], acc[j % MT], 0, 0, 0);
                 }
-                static_assert(APG == XPG, "one accumulator product per X-chain step");
-                if (g + 1 < NG) {
+                if (gg + 1 < NGT) {
                     // issue order: the next group's reads (3 per 2 MFMAs) between this group's MFMAs
 #pragma unroll
                     for (int i = 0; i < XPG; ++i) {
@@ -297,7 +318,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * XPG, 0);
                 }
             }
-            load_consts(sb_next);
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) load_consts(u, sb_next + u * SLOTB);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(LV_RS_PRIO_V);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -337,22 +359,31 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     }
 }
 
-template <int D>
+static int rs_units() {   // LVATTN_DKDV_UNITS=1|2: 32-row units per iteration (read once)
+    static const int n = [] {
+        const char* e = getenv("LVATTN_DKDV_UNITS");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return n;
+}
+
+template <int D, int NSL>
 static void launch_rs(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 grid((unsigned)((int64_t)p.n_blocks * p.hkv)), block(512);
-    size_t lds = (size_t)5 * (2 * 32 * D * 2 + 8 * 256) + 2 * 4 * 2048;  // ring slots + two P buffers
+    size_t lds = (size_t)4 * NSL * (2 * 32 * D * 2 + 256) + (size_t)NSL * 4 * 2048;  // ring slots + P buffers
     if (causal) {
-        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, false>), grid, block, lds, stream, p);
+        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, true, NSL>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, false, NSL>), grid, block, lds, stream, p);
     } else {
-        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, false, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, false, false>), grid, block, lds, stream, p);
+        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, false, true, NSL>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, false, false, NSL>), grid, block, lds, stream, p);
     }
 }
 
 int lv_launch_bwd_dkdv_rs(const BwdParams& p, int d, int causal, int accum, hipStream_t stream) {
     if (p.n_blocks <= 0) return 0;
-    if (d == 128) launch_rs<128>(p, causal, accum, stream);
-    else launch_rs<64>(p, causal, accum, stream);
+    const int two = rs_units() == 2;
+    if (d == 128) { if (two) launch_rs<128, 2>(p, causal, accum, stream); else launch_rs<128, 1>(p, causal, accum, stream); }
+    else { if (two) launch_rs<64, 2>(p, causal, accum, stream); else launch_rs<64, 1>(p, causal, accum, stream); }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -155,3 +155,29 @@ def test_fusion_attention_layouts_agree():
     assert _rel(o_bsnd[1], ref) <= 2e-2
     with pytest.raises(NotImplementedError):
         npu_fusion_attention(q, k, v, n, "BSND", keep_prob=0.9)
+
+
+def test_logit_mask_selection_matches_masked_select():
+    """Row selection of the --logit-mask path against torch.masked_select, the form the reference writes
+    (gpt_vl_model.py:312, :357); bit-exact."""
+    from long_vita_amd import lm_head
+    g = torch.Generator().manual_seed(5)
+    s, c, vocab = 1000, 256, 512
+    hidden = torch.randn(s, 1, c, generator=g).to(torch.bfloat16)
+    labels = torch.randint(0, vocab, (1, s), generator=g)
+    mask = torch.rand(1, s, generator=g) < 0.07
+    want_h = torch.masked_select(hidden, mask.transpose(0, 1).unsqueeze(2)).reshape(-1, 1, c)
+    want_l = torch.masked_select(labels, mask).reshape(1, -1)
+    got_h = lm_head.select_hidden_states(hidden.cuda(), mask.cuda())
+    got_l = lm_head.select_labels(labels.cuda(), mask.cuda())
+    assert torch.equal(got_h.cpu(), want_h) and torch.equal(got_l.cpu(), want_l)
+    w = torch.randn(vocab, c, generator=g).to(torch.bfloat16)
+    logits = lm_head.masked_logits(hidden.cuda(), w.cuda(), mask.cuda())
+    ref = want_h.float() @ w.float().t()
+    assert logits.shape == (int(mask.sum()), 1, vocab)
+    assert (logits.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    # generation: one position per row, taken modulo the local length under context parallelism
+    toks = torch.zeros(1, 64, dtype=torch.int64)
+    assert lm_head.logit_mask_for_context(toks, 40, 1).nonzero().tolist() == [[0, 39]]
+    assert lm_head.logit_mask_for_context(toks, 64 * 3 + 5, 4).nonzero().tolist() == [[0, 4]]
+    assert lm_head.logit_mask_for_context(toks, 128, 2).nonzero().tolist() == [[0, 63]]   # index -1, as the reference
