@@ -111,13 +111,17 @@ def cpu_baseline(seq, rows=1024, heads=(0, 1)):
     def run():
         return A.eager_attention(q, k, v, mask, math.sqrt(D))
     run()  # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    run()
-    dt = time.perf_counter() - t0
+    reps, total = 0, 0.0
+    while total < 12.0 and reps < 16:      # about 10-20 s of CPU work, bounded
+        t0 = time.perf_counter()
+        run()
+        total += time.perf_counter() - t0
+        reps += 1
+    dt = total / reps
     full = dt * (seq / rows) * (HQ / len(heads))
     return {"value": seq / full, "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{rows} query rows x {seq} keys x {len(heads)} of {HQ} heads, fp32 eager baddbmm/softmax/bmm, "
-                      f"{dt:.2f}s measured, extrapolated linearly in rows x heads"}
+                      f"{reps} passes, {total:.1f}s measured, extrapolated linearly in rows x heads"}
 
 
 def profiled_traffic(summary_name, kernel):
