@@ -17,6 +17,10 @@
 // group A requests K tiles, group B V tiles, each wave 1/4 of a tile per VALU phase; a counted
 // s_waitcnt vmcnt before the phase-ending barrier leaves the newest request in flight.
 #include "internal.h"
+
+#ifndef LV_PP_MAP
+#define LV_PP_MAP 2   // workgroup -> (KV head, query block, head) mapping: 0 = plain order, 1 / 2 = XCD-aware (see the kernel)
+#endif
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -68,11 +72,26 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
     const int r = lane & 31;
     const int h = lane >> 5;
 
+#if LV_PP_MAP == 0
     const int bid = blockIdx.x;
     const int hg = bid % p.group;
     const int rest = bid / p.group;
     const int blk = rest % p.n_blocks;
     const int kvh = rest / p.n_blocks;
+#else
+    // Workgroup i runs on XCD i % 8 (each XCD has its own L2).  The query heads of one (KV head, query block)
+    // unit take consecutive slots of ONE XCD, so they stream the same K / V tiles through the same L2 side by side;
+    // units go round the XCDs in heaviest-first order.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int hg = slot % p.group;
+    const int unit = (slot / p.group) * 8 + xcd;
+    if (unit >= p.n_blocks * p.hkv) return;
+#if LV_PP_MAP == 1
+    const int blk = unit / p.hkv, kvh = unit % p.hkv;      // with 8 KV heads: one KV head per XCD
+#else
+    const int blk = unit % p.n_blocks, kvh = unit / p.n_blocks;
+#endif
+#endif
     const int head = kvh * p.group + hg;
 
     const AttnDesc dsc = p.desc[blk];
@@ -347,7 +366,11 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 
 template <int D>
 static void launch_pp(const FwdParams& p, int causal, hipStream_t stream) {
+#if LV_PP_MAP == 0
     dim3 grid((unsigned)((int64_t)p.n_blocks * p.hq)), block(512);
+#else
+    dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(512);
+#endif
     size_t lds = (size_t)3 * 2 * 64 * D * 2;  // 3 slots x (K tile + V tile)
     if (causal) hipLaunchKernelGGL((lv_fwd_pp_kernel<D, true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((lv_fwd_pp_kernel<D, false>), grid, block, lds, stream, p);
