@@ -61,7 +61,6 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     constexpr int SLOTB = 2 * QTILE + 256;        // [Q rows][dO rows][32 lse, 32 delta f32]
     constexpr int RPP = 64 / CPR;                 // rows per 1-KiB piece
     constexpr int PPW = (2 * QTILE / 1024) / NW;  // pieces per wave per unit: 2 (d=128) or 1 (d=64)
-    constexpr int LPI = PPW + 1;                  // loads per wave per unit
     constexpr int PBUF = 4 * 2048;                // P of one unit: 4 wave pairs x (2 halves x 64 lanes x 16 bytes)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,9 +124,12 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
     const int64_t x_step_head = x_hs * 2;
     const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
-    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31.  Every wave
-    // writes the same 256 bytes of the slot (one copy, identical data), which keeps the load count per
-    // wave uniform.
+    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31, one request per
+    // unit for the whole workgroup: V-wave `pair` brings them for the units u with u % NSL == pair (a
+    // V-wave, because the V-waves run ahead: what they have waited for is there for both roles).  Each
+    // direct-to-LDS request costs its wave (and its SIMD) far more issue time than an ordinary load, so
+    // they are not duplicated.
+    const bool c_wave = !is_k && pair < NSL;
     const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
     const int64_t c_step_head = p.lse_stride;
     const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
         const uint32_t dst = ld_slot + (is_k ? QTILE : 0) + PPW * pair * 1024;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) rs_dma16(rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
-        rs_dma4(ld_c + (partial ? c_part : 0), ld_slot + 2 * QTILE);
+        if (c_wave && (ld_n % NSL) == pair) rs_dma4(ld_c + (partial ? c_part : 0), ld_slot + 2 * QTILE);
         // past the last unit the stream stays where it is: the loop's unconditional requests re-fetch that
         // unit (into slots only dead units read)
         const bool adv = (++ld_n < nunits);
@@ -280,7 +282,9 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
             for (int u = 0; u < NSL; ++u) issue_dma();
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSL * LPI) : "memory");
+            // leave this iteration's requests in flight, everything older has landed
+            if (c_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSL * PPW + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSL * PPW) : "memory");
             __builtin_amdgcn_sched_barrier(0);
 
             // ================= MFMA(it): X of the next iteration's units and acc += A_cols^T Y =================
