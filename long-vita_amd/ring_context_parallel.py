@@ -282,3 +282,43 @@ def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask
     d = q.shape[-1] // n
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
     return _RingAttnFunction.apply(q, k, v, eng, n, float(scale))
+
+
+def merge_partial_attention(outs: torch.Tensor, lses: torch.Tensor) -> torch.Tensor:
+    """outs [n, ..., d] fp32 (each normalised over its own keys), lses [n, ...] (natural log of its softmax
+    denominator, -inf for an empty key set) -> attention over the union of the key sets, [..., d] fp32."""
+    m = lses.max(dim=0).values
+    m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    w = torch.exp(lses - m)                      # exp(-inf) = 0 drops empty parts
+    den = w.sum(dim=0)
+    num = (w.unsqueeze(-1) * outs).sum(dim=0)
+    return num / torch.where(den > 0, den, torch.ones_like(den)).unsqueeze(-1)
+
+
+def decode_context_parallel(q, k_local, v_local, scale: float, group=None, cp_size: int = 1, partial=None):
+    """One new token per sequence against a KV cache that is SHARDED over the context-parallel group (after a ring
+    prefill every rank holds the keys / values of its own zig-zag chunks; which positions a rank holds does not
+    matter, the new token sees them all).  q [b, hq, d] (the same on every rank), k_local / v_local [b, k_loc, hkv, d]
+    -> out [b, hq, d].  Each rank runs the incremental kernel over its shard, then one all_gather of (out, lse)
+    -- (d + 1) floats per head -- and a log-sum-exp merge.  The reference has no counterpart: under context
+    parallelism its generation loop runs the whole prompt again for every token
+    (tasks/inference/text_generation/utils.py:351-385).
+    ``partial(q, k, v, scale) -> (out, lse)`` replaces the HIP kernel in CPU tests."""
+    if partial is None:
+        from . import ops
+
+        def partial(q_, k_, v_, s_):
+            return ops.decode_attention(q_, k_, v_, s_, return_lse=True)
+    b, hq, d = q.shape
+    if k_local.shape[1] > 0:
+        out, lse = partial(q, k_local, v_local, scale)
+    else:   # a rank may hold nothing yet
+        out = torch.zeros((b, hq, d), dtype=q.dtype, device=q.device)
+        lse = torch.full((b, hq), float("-inf"), dtype=torch.float32, device=q.device)
+    if cp_size == 1:
+        return out
+    pack = torch.cat([out.float(), lse.float().unsqueeze(-1)], dim=-1).contiguous()
+    parts = [torch.empty_like(pack) for _ in range(cp_size)]
+    dist.all_gather(parts, pack, group=group)
+    parts = torch.stack(parts)
+    return merge_partial_attention(parts[..., :d], parts[..., d]).to(q.dtype)

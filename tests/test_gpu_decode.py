@@ -117,3 +117,22 @@ def test_kv_cache_branch_of_flash_attention_forward():
     for i in range(b):
         ref, _ = A.varlen_attention(q[:, i], k[:, i], v[:, i], [0, S], scale, True)
         assert np.abs(got[:, i] - ref).max() <= REL_TOL * np.abs(ref).max()
+
+
+def test_sharded_cache_partials_merge_to_the_whole():
+    """Two zig-zag shards of a cache through the incremental kernel, merged in log-sum-exp form
+    (what decode_context_parallel does after its all_gather), against the oracle over the whole cache."""
+    from long_vita_amd import ops
+    from long_vita_amd.ring_context_parallel import merge_partial_attention
+    b, hq, hkv, d, S, cp = 2, 10, 2, 128, 4096, 2
+    q, k, v = _rnd(b, hq, d, seed=21), _rnd(b, S, hkv, d, seed=22), _rnd(b, S, hkv, d, seed=23)
+    scale = 1.0 / math.sqrt(d)
+    chunks = torch.arange(S).view(2 * cp, -1)
+    outs, lses = [], []
+    for r in range(cp):
+        idx = torch.cat([chunks[r], chunks[2 * cp - 1 - r]])
+        o, l = ops.decode_attention(q.cuda(), k[:, idx].cuda(), v[:, idx].cuda(), scale, return_lse=True)
+        outs.append(o.float())
+        lses.append(l)
+    merged = merge_partial_attention(torch.stack(outs), torch.stack(lses))
+    _check(merged, None, q, k, v, scale)

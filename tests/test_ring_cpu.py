@@ -103,3 +103,48 @@ def test_step_rectangles_cover_causal_triangle():
                             continue
                         cover[own[qi], theirs[ki]] += 1
         assert (cover == np.tril(np.ones_like(cover))).all(), cp
+
+
+def _oracle_partial(q, k, v, scale):
+    outs, lses = [], []
+    for i in range(q.shape[0]):
+        o, l = A.block_attention(q[i][None], k[i], v[i], scale, None)
+        outs.append(torch.from_numpy(o[0]).float())
+        lses.append(torch.from_numpy(l[:, 0]).float())
+    return torch.stack(outs), torch.stack(lses)
+
+
+def _gloo_decode_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from long_vita_amd.ring_context_parallel import decode_context_parallel
+    g = torch.Generator().manual_seed(3)
+    b, hq, hkv, d, S = 2, 4, 2, 8, 40
+    q, k, v = torch.randn(b, hq, d, generator=g), torch.randn(b, S, hkv, d, generator=g), torch.randn(b, S, hkv, d, generator=g)
+    # the zig-zag shard of the cache this rank holds after a ring prefill
+    idx = torch.cat([torch.arange(S).view(2 * world, -1)[rank], torch.arange(S).view(2 * world, -1)[2 * world - 1 - rank]])
+    out = decode_context_parallel(q, k[:, idx], v[:, idx], 0.3, dist.group.WORLD, world, partial=_oracle_partial)
+    # second call: rank 1 holds nothing (an empty shard must drop out of the merge)
+    kk = k if rank == 0 else k[:, :0]
+    vv = v if rank == 0 else v[:, :0]
+    out2 = decode_context_parallel(q, kk, vv, 0.3, dist.group.WORLD, world, partial=_oracle_partial)
+    torch.save({"out": out, "out2": out2}, os.path.join(out_dir, f"d{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_decode_over_sharded_cache_gloo_world2(tmp_path):
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_decode_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(3)
+    b, hq, hkv, d, S = 2, 4, 2, 8, 40
+    q, k, v = torch.randn(b, hq, d, generator=g), torch.randn(b, S, hkv, d, generator=g), torch.randn(b, S, hkv, d, generator=g)
+    ref, _ = _oracle_partial(q, k, v, 0.3)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"d{r}.pt"), weights_only=True)
+        np.testing.assert_allclose(res["out"].numpy(), ref.numpy(), atol=2e-5)
+        np.testing.assert_allclose(res["out2"].numpy(), ref.numpy(), atol=2e-5)
