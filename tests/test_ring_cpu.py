@@ -49,6 +49,31 @@ def test_ring_virtual_ranks_forward_backward(cp):
         np.testing.assert_allclose(got.numpy(), ref, atol=1e-4)
 
 
+@pytest.mark.parametrize("cp", [2, 4])
+def test_ring_virtual_ranks_full_attention(cp):
+    """cp_attention_mask_type other than 'causal': every rank attends to every block (no zig-zag needed, any
+    equal split works); forward and backward against the oracle's dense attention."""
+    from long_vita_amd.ring_context_parallel import RingAttention
+    S, Hq, Hkv, D = 48, 4, 2, 8
+    q, k, v, do = _problem(S, Hq, Hkv, D, seed=5)
+    scale = 0.3
+    ref_o, ref_lse = A.varlen_attention(q, k, v, [0, S], scale, causal=False)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, [0, S], scale, causal=False)
+    fabric = LoopbackFabric(cp)
+    n = S // cp
+
+    def body(r):
+        eng = RingAttention(None, cp, r, causal=False, backend=CheckerBackend(), comm=LoopbackComm(fabric, r))
+        ql, kl, vl, dl = (x[r * n:(r + 1) * n].reshape(n, 1, -1) for x in (q, k, v, do))
+        out, lse = eng.forward(ql, kl, vl, Hq, scale, return_state=True)
+        dq, dk, dv = eng.backward(ql, kl, vl, out, lse, dl, Hq, scale)
+        return out[:, 0], dq[:, 0], dk[:, 0], dv[:, 0]
+    res = run_virtual_ranks(cp, body)
+    for idx, ref, H in ((0, ref_o, Hq), (1, rdq, Hq), (2, rdk, Hkv), (3, rdv, Hkv)):
+        got = torch.cat([r[idx] for r in res]).reshape(S, H, D)
+        np.testing.assert_allclose(got.numpy(), ref, atol=1e-4)
+
+
 def _gloo_worker(rank, world, port, S, Hq, Hkv, D, scale, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
