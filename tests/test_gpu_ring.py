@@ -50,3 +50,56 @@ def test_ring_hip_backend_matches_full_causal(cp, S):
     for idx, ref, H in ((2, rdq, Hq), (3, rdk, Hkv), (4, rdv, Hkv)):
         got = unzigzag([r[idx] for r in res], cp).reshape(S, H, D)
         assert rel(got, ref) <= REL_TOL, idx
+
+
+def _mp_worker(rank, world, port, S, Hq, Hkv, D, scale, out_dir):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from long_vita_amd.ring_context_parallel import ringattn_context_parallel
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    dev = torch.device("cuda", 0)
+    ql, kl, vl, dl = (zigzag_local(x, world, rank).reshape(S // world, 1, -1).to(dev) for x in (q, k, v, do))
+    ql.requires_grad_(True); kl.requires_grad_(True); vl.requires_grad_(True)
+    cp_para = dict(causal=True, cp_group=dist.group.WORLD, cp_size=world, rank=rank, cp_global_ranks=list(range(world)),
+                   cp_group_for_send_recv_overlap=None, pse=None, pse_type=None)
+    out = ringattn_context_parallel(ql, kl, vl, Hq, cp_para, scale, None, 0.)
+    out.backward(dl)
+    torch.cuda.synchronize()
+    torch.save({"out": out.detach().cpu(), "dq": ql.grad.cpu(), "dk": kl.grad.cpu(), "dv": vl.grad.cpu()},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ring_two_processes_one_gpu_torch_distributed(tmp_path):
+    """The shipped transport class (torch.distributed point-to-point posted on a side stream, completion handed to
+    the compute stream as an event) and the HIP backend in two real processes.  Both ranks sit on the single GPU
+    of the test box, so the process group is gloo (RCCL refuses two ranks on one device); on a multi-GPU node
+    the same code runs with backend nccl (bench.py --gpus N)."""
+    import os
+    import torch.multiprocessing as mp
+    S, Hq, Hkv, D, world = 2048, 10, 2, 128, 2
+    scale = A.default_scale(D)
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_mp_worker, args=(world, port, S, Hq, Hkv, D, scale, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    ref_o, _ = A.varlen_attention(q, k, v, [0, S], scale)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, [0, S], scale)
+    res = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=True) for r in range(world)]
+    for name, ref, H in (("out", ref_o, Hq), ("dq", rdq, Hq), ("dk", rdk, Hkv), ("dv", rdv, Hkv)):
+        got = unzigzag([r[name][:, 0] for r in res], world).reshape(S, H, D)
+        assert rel(got, ref) <= REL_TOL, name
