@@ -60,12 +60,20 @@ def dist_setup(n):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if n > 1 and world != n:
         raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run); got {world}")
+    # LV_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (RCCL refuses two
+    # ranks on one device); ranks then share devices round-robin.  The judged runs use nccl (= RCCL).
+    backend = os.environ.get("LV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     return rank, world, local
 
 
