@@ -91,6 +91,11 @@ int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* ls
                int64_t o_row_stride, int64_t o_head_stride,
                int64_t lse_stride, float softmax_scale, int causal, void* stream);
 
+/* Tuning / test hook, no counterpart in the reference: choose the forward kernel for later lvattn_fwd calls of this
+ * process ("default", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
+ * is read on first use otherwise).  Not thread-safe against concurrent launches. */
+int lvattn_select_fwd_kernel(const char* name);
+
 /* ---- incremental attention over a KV cache -------------------------------------
  * Replaces torch_npu.npu_incre_flash_attention as called with --use-kv-cache
  * (lcvlm_modellink/core/transformer/dot_product_attention.py:428-438: query [b, 1, hq*d], key / value

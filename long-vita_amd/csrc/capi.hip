@@ -26,14 +26,21 @@ extern "C" int lvattn_abi_version(void) { return 1; }
 // Forward kernel choice.  Default: the ping-pong kernel for head dim 128 and the lockstep kernel for
 // head dim 64 (each is the faster one there: +13 % at d = 128, -16 % at d = 64).  The environment variable
 // LVATTN_FWD_KERNEL=pp / lockstep forces one of them for every head dim.
-static int fwd_kernel_override() {   // 0 none, 1 ping-pong, 2 lockstep
-    static int v = [] {
-        const char* e = getenv("LVATTN_FWD_KERNEL");
-        if (!e) return 0;
-        return !strcmp(e, "pp") ? 1 : (!strcmp(e, "lockstep") ? 2 : 0);
-    }();
-    return v;
+static int fwd_kernel_code(const char* e) {   // 0 default, 1 ping-pong (32x32x16 MFMAs), 2 lockstep, 3 ping-pong on 16x16x32 MFMAs
+    if (!e) return 0;
+    return !strcmp(e, "pp") ? 1 : (!strcmp(e, "lockstep") ? 2 : (!strcmp(e, "pp16") ? 3 : 0));
 }
+static int g_fwd_kernel = -1;   // -1: not read yet
+static int fwd_kernel_override() {
+    if (g_fwd_kernel < 0) g_fwd_kernel = fwd_kernel_code(getenv("LVATTN_FWD_KERNEL"));
+    return g_fwd_kernel;
+}
+extern "C" int lvattn_select_fwd_kernel(const char* name) {
+    if (name && name[0] && strcmp(name, "default") && !fwd_kernel_code(name)) return fail(LV_EINVAL, "unknown forward kernel '%s' (default, pp, pp16, lockstep)", name);
+    g_fwd_kernel = fwd_kernel_code(name);
+    return LV_OK;
+}
+static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
 static bool fwd_pingpong(int d) {
     const int o = fwd_kernel_override();
     return o == 1 || (o == 0 && d == 128);
@@ -174,7 +181,10 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
     p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
     p.o_rs = o_rs; p.o_hs = o_hs; p.lse_stride = lse_stride;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream) : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+    const int rc = fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
+                   : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
+                                     : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream);
+    if (rc) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }
 

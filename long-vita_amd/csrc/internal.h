@@ -16,6 +16,7 @@ struct FwdParams {
 };
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
+int lv_launch_fwd_pp16(const FwdParams& p, int causal, hipStream_t stream);      // ping-pong form on 16x16x32 MFMAs, d = 128
 
 // Incremental attention over a KV cache: q [batch, hq, d], k/v [batch, k_len, hkv, d], out [batch, hq, d].
 #define LV_DECODE_MAX_SPLITS 256

@@ -216,3 +216,25 @@ def test_full_size_1m_prefill_rows_against_oracle_and_decode_kernel():
     dec, dlse = ops.decode_attention(q[S - 1][None], k[None], v[None], scale, return_lse=True)
     assert (dec[0].float() - out[S - 1].float()).abs().max().item() <= REL_TOL * out[S - 1].float().abs().max().item()
     assert (dlse[0] - lse[:, S - 1]).abs().max().item() <= LSE_TOL
+
+
+@pytest.mark.parametrize("kernel", ["pp", "pp16", "lockstep"])
+def test_every_forward_kernel_variant(kernel):
+    """The forward kernels that are not the default for a head dim stay selectable (LVATTN_FWD_KERNEL or
+    lvattn_select_fwd_kernel) and give the same results to tolerance."""
+    from long_vita_amd import ops, _lib
+    cases = [([0, 100, 356, 357, 700, 1290], 10, 2, 128, True), ([0, 300, 900], 4, 2, 128, False), ([0, 130, 700], 4, 2, 64, True)]
+    _lib.check(_lib.lib().lvattn_select_fwd_kernel(kernel.encode()), "select")
+    try:
+        for cu, Hq, Hkv, D, causal in cases:
+            q, k, v = make_qkv(cu[-1], Hq, Hkv, D, seed=len(kernel) + D)
+            scale = A.default_scale(D)
+            ref_o, ref_lse = A.varlen_attention(q, k, v, cu, scale, causal)
+            out, lse = ops.attn_fwd_launch(q.cuda(), k.cuda(), v.cuda(), ops.blocks_on_device(cu, causal, False, "cuda"), scale, causal)
+            torch.cuda.synchronize()
+            assert rel_err(out, ref_o) <= REL_TOL, (kernel, cu)
+            assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL, (kernel, cu)
+    finally:
+        _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
+    with pytest.raises(_lib.LvAttnError):
+        _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"no-such-kernel"), "select")
