@@ -21,6 +21,9 @@
 
 typedef __attribute__((address_space(3))) char lds_char;
 
+#ifndef LV_RS_MAP
+#define LV_RS_MAP 1   // key block -> workgroup order: 0 = KV-head-major, 1 = KV head fastest (one head group per XCD)
+#endif
 #ifndef LV_RS_PRIO_M
 #define LV_RS_PRIO_M 2   // s_setprio level in the matrix phase
 #endif
@@ -77,8 +80,17 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     const int h = lane >> 5;
 
     const int bid = blockIdx.x;
+#if LV_RS_MAP == 0
     const int blk = bid % p.n_blocks;
     const int kvh = bid / p.n_blocks;
+#else
+    // Workgroup i runs on XCD i % 8 (own L2 each).  Key blocks are dealt to the XCDs by KV head (KV head = unit % hkv:
+    // with 8 KV heads one per XCD), so that an XCD's L2 only ever holds the Q / dO rows of one head group.
+    const int unit = (bid >> 3) * 8 + (bid & 7);
+    if (unit >= p.n_blocks * p.hkv) return;
+    const int blk = unit / p.hkv;
+    const int kvh = unit % p.hkv;
+#endif
 
     const AttnDesc dsc = p.desc[blk];
     const int k_row0 = dsc.a_row0, k_rows = dsc.a_rows;
@@ -373,7 +385,7 @@ static int rs_units() {   // LVATTN_DKDV_UNITS=1|2: 32-row units per iteration (
 
 template <int D, int NSL>
 static void launch_rs(const BwdParams& p, int causal, int accum, hipStream_t stream) {
-    dim3 grid((unsigned)((int64_t)p.n_blocks * p.hkv)), block(512);
+    dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8)), block(512);
     size_t lds = (size_t)4 * NSL * (2 * 32 * D * 2 + 256) + (size_t)NSL * 4 * 2048;  // ring slots + P buffers
     if (causal) {
         if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, true, NSL>), grid, block, lds, stream, p);
