@@ -216,3 +216,37 @@ def test_vision_model_chunks_of_256_images():
     whole = m(images=img)
     assert whole.shape == (258, 1, 64) and not whole.requires_grad
     assert torch.equal(whole[:256], m.forward_once(img[:256])) and torch.equal(whole[256:], m.forward_once(img[256:]))
+
+
+def test_image_to_llm_embedding_end_to_end():
+    """One 448-pixel image through the vision model at InternViT-300M width (2 layers to keep the oracle quick):
+    patch projection -> 1025 tokens -> tower -> class-token drop + pixel shuffle -> 256 tokens -> projector -> 5120 wide,
+    then scattered into the LLM's embedding rows at the positions the data pipeline assigns to the image
+    ([START] + 256 x CONTEXT + [END], dataset_qwen2.py:676-697; language_model_embedding.py:114-134)."""
+    from long_vita_amd import intern_vit as iv, vision_model as vmod, vision, packing
+    cfg = iv.InternViTConfig(num_layers=2)
+    torch.manual_seed(11)
+    m = vmod.MegatronVisionModel(hidden_size=5120, vit_config=cfg)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("ls1") or name.endswith("ls2"):
+                prm.copy_(torch.randn_like(prm) * 0.3)
+        m = m.to(torch.bfloat16)
+    sd = {k: v.detach().float() for k, v in m.state_dict().items()}
+    img = _bf(1, 3, 448, 448, seed=61)
+    want = vit_ref.vision_model_forward(img.float(), sd, cfg.num_attention_heads, cfg.patch_dim, cfg.layernorm_epsilon)
+    feats = m.cuda()(images=img.cuda())
+    assert feats.shape == (1, 256, 5120)
+    _close(feats, want)
+
+    seq, cur_len = 8192, 37
+    image_indices, new_len = packing.frame_token_span(cur_len, 256)
+    assert new_len == cur_len + 258
+    emb = _bf(1, seq, 5120, seed=62).cuda()
+    before = emb.clone()
+    out = vision.scatter_external_features(emb, {"features": feats.detach(), "indices": image_indices.cuda()})
+    pos = image_indices[1, 0]
+    assert torch.equal(out[0, pos], feats.detach()[0])                      # the 256 context rows, bit for bit
+    keep = torch.ones(seq, dtype=torch.bool)
+    keep[pos] = False
+    assert torch.equal(out[0, keep], before[0, keep])                       # every other row untouched
