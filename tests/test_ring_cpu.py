@@ -173,3 +173,42 @@ def test_decode_over_sharded_cache_gloo_world2(tmp_path):
         res = torch.load(os.path.join(str(tmp_path), f"d{r}.pt"), weights_only=True)
         np.testing.assert_allclose(res["out"].numpy(), ref.numpy(), atol=2e-5)
         np.testing.assert_allclose(res["out2"].numpy(), ref.numpy(), atol=2e-5)
+
+
+def _gloo_vision_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from long_vita_amd.vision_parallel import encode_images_context_parallel, images_needed_by_rank
+    S, T, n_img = 256, 8, 7
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(n_img, 3, 4, 4, generator=g)
+    # a video at the front of the sample: consecutive 10-token frames (T context tokens each), one straddling a chunk edge
+    starts = torch.tensor([1, 11, 21, 27, 60, 61 + 64, 200])
+    ind_s = starts[:, None] + torch.arange(T)[None]
+    ext = torch.stack([torch.zeros_like(ind_s), ind_s])
+    calls = []
+
+    def encode(x):
+        calls.append(x.shape[0])
+        return x.reshape(x.shape[0], 1, -1)[:, :, :6].repeat(1, T, 1) * 2.0 + 1.0   # [n, T, 6], a pure function of the image
+    out = encode_images_context_parallel(images, ext, S, world, rank, encode, dist.group.WORLD)
+    need = images_needed_by_rank(ext, S, world, rank)
+    torch.save({"out": out, "need": need, "calls": torch.tensor(calls), "ref": encode(images[need])}, os.path.join(out_dir, f"v{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_image_encode_dealt_over_cp_ranks_gloo_world2(tmp_path):
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_vision_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    total = 0
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"v{r}.pt"), weights_only=True)
+        assert torch.equal(res["out"], res["ref"])          # what the reference's per-rank encode would hold
+        assert int(res["calls"][0]) in (3, 4)               # 7 images dealt 4 + 3, whatever each rank needs
+        total += int(res["calls"][0])
+    assert total == 7
