@@ -233,27 +233,43 @@ __global__ __launch_bounds__(256, 2) void lv_decode_kernel(DecodeParams p) {
     }
 }
 
-// out[b][head][:] = sum_s exp(lse_s - max) O_s / sum_s exp(lse_s - max); one block per (b, head), one thread per column.
+// out[b][head][:] = sum_s exp(lse_s - max) O_s / sum_s exp(lse_s - max); one block per (b, head).  The splits'
+// log-sum-exps are fetched once by the block (thread s <-> split s) and turned into weights in LDS, then thread c sums
+// column c over the splits with independent loads: two memory round trips instead of a chain of 2 x n_split.
 __global__ __launch_bounds__(128) void lv_decode_combine_kernel(DecodeParams p, int d) {
+    __shared__ float w_s[LV_DECODE_MAX_SPLITS];
+    __shared__ float red[2];
+    const int tid = threadIdx.x;
     const int bhq = blockIdx.x;               // b * hq + head
     const int b = bhq / p.hq, head = bhq % p.hq;
     const int kvh = head / p.group, g = head % p.group;
     const int64_t bh = (int64_t)b * p.hkv + kvh;
     const float* lse = p.part_lse + bh * p.n_split * p.group + g;
     float mx = -INFINITY;
-    for (int s = 0; s < p.n_split; ++s) mx = fmaxf(mx, lse[(int64_t)s * p.group]);
-    const int col = threadIdx.x;
-    if (col >= d) return;
-    float acc = 0.f, wsum = 0.f;
-    if (mx > -INFINITY) {
-        for (int s = 0; s < p.n_split; ++s) {
-            const float wgt = __expf(lse[(int64_t)s * p.group] - mx);
-            wsum += wgt;
-            acc += wgt * p.part_o[((bh * p.n_split + s) * p.group + g) * d + col];
-        }
+    for (int s = tid; s < p.n_split; s += 128) {
+        const float v = lse[(int64_t)s * p.group];
+        w_s[s] = v;
+        mx = fmaxf(mx, v);
     }
-    p.o[(int64_t)b * p.o_bs + (int64_t)head * p.o_hs + col] = (__bf16)(wsum > 0.f ? acc / wsum : 0.f);
-    if (p.lse && col == 0) p.lse[(int64_t)b * p.hq + head] = mx > -INFINITY ? mx + __logf(wsum) : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
+    for (int s = tid; s < p.n_split; s += 128) w_s[s] = mx > -INFINITY ? __expf(w_s[s] - mx) : 0.f;
+    __syncthreads();
+    if (tid >= d) return;
+    const float* po = p.part_o + (bh * p.n_split * p.group + g) * d + tid;
+    const int64_t step = (int64_t)p.group * d;
+    float acc = 0.f, wsum = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < p.n_split; ++s) {
+        const float wgt = w_s[s];
+        wsum += wgt;
+        acc += wgt * po[s * step];
+    }
+    p.o[(int64_t)b * p.o_bs + (int64_t)head * p.o_hs + tid] = (__bf16)(wsum > 0.f ? acc / wsum : 0.f);
+    if (p.lse && tid == 0) p.lse[(int64_t)b * p.hq + head] = mx > -INFINITY ? mx + __logf(wsum) : -INFINITY;
 }
 
 int lv_launch_decode(const DecodeParams& p, int d, hipStream_t stream) {
