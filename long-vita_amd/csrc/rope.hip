@@ -23,6 +23,15 @@ __device__ __forceinline__ float rb(float v) {
 __device__ __forceinline__ __bf16 as_bf16(float rounded) {  // `rounded` already has zero low bits
     return __builtin_bit_cast(__bf16, (uint16_t)(__float_as_uint(rounded) >> 16));
 }
+// The same rounding by the hardware converter, two values per instruction (round to nearest even is the
+// default mode).  As asm so that the value really passes through bf16 here.
+__device__ __forceinline__ uint32_t rb2(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xFFFF0000u); }
 
 template <bool CONJ>
 __global__ __launch_bounds__(256) void lv_rope_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ out,
@@ -58,20 +67,24 @@ __global__ __launch_bounds__(256) void lv_rope_kernel(const __bf16* __restrict__
         const bf16x8 c2 = *reinterpret_cast<const bf16x8*>(cos_tab + trow * rot + c0 + half);
         const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sin_tab + trow * rot + c0);
         const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(sin_tab + trow * rot + c0 + half);
-        bf16x8 o1, o2;
+        u32x4 o1, o2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float a = (float)x1[i], b = (float)x2[i];
-            if (!CONJ) {
-                o1[i] = as_bf16(rb(rb(a * (float)c1[i]) - rb(b * (float)s1[i])));
-                o2[i] = as_bf16(rb(rb(b * (float)c2[i]) + rb(a * (float)s2[i])));
-            } else {
-                o1[i] = as_bf16(rb(rb(a * (float)c1[i]) + rb(b * (float)s2[i])));
-                o2[i] = as_bf16(rb(rb(b * (float)c2[i]) - rb(a * (float)s1[i])));
+        for (int i = 0; i < 8; i += 2) {
+            float r1[2], r2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a = (float)x1[i + e], b = (float)x2[i + e];
+                // each product is rounded on its own (two per converter instruction), then the sum
+                const uint32_t p1 = CONJ ? rb2(a * (float)c1[i + e], b * (float)s2[i + e]) : rb2(a * (float)c1[i + e], b * (float)s1[i + e]);
+                const uint32_t p2 = CONJ ? rb2(b * (float)c2[i + e], a * (float)s1[i + e]) : rb2(b * (float)c2[i + e], a * (float)s2[i + e]);
+                r1[e] = CONJ ? lo_f32(p1) + hi_f32(p1) : lo_f32(p1) - hi_f32(p1);
+                r2[e] = CONJ ? lo_f32(p2) - hi_f32(p2) : lo_f32(p2) + hi_f32(p2);
             }
+            o1[i >> 1] = rb2(r1[0], r1[1]);
+            o2[i >> 1] = rb2(r2[0], r2[1]);
         }
-        *reinterpret_cast<bf16x8*>(op + c0) = o1;
-        *reinterpret_cast<bf16x8*>(op + c0 + half) = o2;
+        *reinterpret_cast<u32x4*>(op + c0) = o1;
+        *reinterpret_cast<u32x4*>(op + c0 + half) = o2;
     }
 }
 
