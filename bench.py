@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "vit_tower", "rope_qk", "decode"])
     ap.add_argument("--seq", type=int, default=0, help="override the sequence length (testing)")
+    ap.add_argument("--heads", default="", help="override 'q_heads,kv_heads' (testing; e.g. 5,1 = one rank's share under TP=8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -93,7 +94,8 @@ def max_over_ranks(x: float, world) -> float:
     return float(t.item())
 
 
-def causal_fwd_flops(lengths, hq=HQ, d=D):
+def causal_fwd_flops(lengths, hq=None, d=D):
+    hq = HQ if hq is None else hq
     return sum(2.0 * d * hq * float(L) * float(L) for L in lengths)
 
 
@@ -149,7 +151,10 @@ def profiled_traffic(summary_name, kernel):
 
 
 def main():
+    global HQ, HKV
     args = parse()
+    if args.heads:
+        HQ, HKV = (int(x) for x in args.heads.split(","))
     rank, world, local = dist_setup(args.gpus)
     from long_vita_amd import ops
     dev = torch.device("cuda", local)
