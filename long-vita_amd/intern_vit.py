@@ -11,8 +11,10 @@ ckpt_converter_intern_vit.py loads with ``load_state_dict``; ``linear_qkv`` keep
 
 Work split: the GEMMs go to the BLAS library through ``torch.nn.functional.linear`` (plain library GEMMs);
 everything between them is a HIP kernel of liblvattn (patch extraction, token assembly, LayerNorm,
-attention straight on the strided qkv buffer, bias + LayerScale + residual, bias + GELU).  Forward only:
-the scripts that use this tower at long context freeze it (``--vision-model-freeze``).
+attention straight on the strided qkv buffer, bias + LayerScale + residual, bias + GELU).  With ``freeze=True``
+(``--vision-model-freeze``, how the long-context stages and the servers run the tower) the forward runs without
+a graph; otherwise every piece is differentiable (HIP backward kernels for attention, LayerNorm and GELU, torch
+for the GEMMs and the small per-column reductions), which is what stage 2 needs.
 """
 from __future__ import annotations
 
@@ -84,8 +86,11 @@ class InternViTTransformerLayer(torch.nn.Module):
         # Megatron layout: per head [q | k | v]; as rows = s, heads = b * np with a head stride of 3 * hn the
         # three operands are strided views of the GEMM output (no copies, no transposes)
         hv = qkv.view(s, b * self.heads, 3 * hn)
-        ctx, _ = ops.attn_fwd_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], desc, 1.0 / math.sqrt(hn), False)
-        proj = F.linear(ctx.view(s * b, h), sa.linear_proj.weight)
+        if torch.is_grad_enabled() and qkv.requires_grad:
+            ctx, _ = ops.varlen_attention(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], [0, s], 1.0 / math.sqrt(hn), False)
+        else:
+            ctx, _ = ops.attn_fwd_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], desc, 1.0 / math.sqrt(hn), False)
+        proj = F.linear(ctx.reshape(s * b, h), sa.linear_proj.weight)
         x1 = ops.bias_scale_residual(proj, sa.linear_proj.bias, self.ls1, hidden_states.view(s * b, h))
         y = ops.layernorm(x1, self.pre_mlp_layernorm.weight, self.pre_mlp_layernorm.bias, self.eps)
         act = ops.bias_gelu(F.linear(y, mlp.linear_fc1.weight), mlp.linear_fc1.bias)
@@ -100,9 +105,10 @@ class _Decoder(torch.nn.Module):
 
 
 class InternViTModel(torch.nn.Module):
-    def __init__(self, cfg: InternViTConfig | None = None, vision_context_parallel: bool = False):
+    def __init__(self, cfg: InternViTConfig | None = None, vision_context_parallel: bool = False, freeze: bool = True):
         super().__init__()
         cfg = cfg or InternViTConfig()
+        self.freeze = freeze
         if vision_context_parallel:
             raise NotImplementedError("vision context parallelism (intern_vit_model.py:218-233) is not built")
         if not cfg.add_class_token:
@@ -124,15 +130,22 @@ class InternViTModel(torch.nn.Module):
         k = w[0].numel()
         kpad = (k + 15) // 16 * 16
         key = (w.data_ptr(), w._version, w.dtype, w.device)
+        if torch.is_grad_enabled() and w.requires_grad:
+            return F.pad(w.reshape(w.shape[0], k), (0, kpad - k))      # differentiable, rebuilt per step
         if self._wpad is None or self._wpad[0] != key:
             wp = torch.zeros((w.shape[0], kpad), dtype=w.dtype, device=w.device)
             wp[:, :k] = w.detach().reshape(w.shape[0], k)
             self._wpad = (key, wp)
         return self._wpad[1]
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor, attention_mask=None) -> torch.Tensor:
         """x [batch, 3, img_h, img_w] bf16 -> [batch, seq, hidden] (intern_vit_model.py:190-261)."""
+        if self.freeze:
+            with torch.no_grad():
+                return self._forward(x, attention_mask)
+        return self._forward(x, attention_mask)
+
+    def _forward(self, x: torch.Tensor, attention_mask=None) -> torch.Tensor:
         if attention_mask is not None:
             raise NotImplementedError("InternViT attends without a mask (vit_layer_specs.py:84)")
         cfg = self.cfg

@@ -250,7 +250,31 @@ def varlen_attention(q, k, v, cu_seqlens: Sequence[int], scale: float | None = N
 # ---------------------------------------------------------------------------
 # data movement
 # ---------------------------------------------------------------------------
+class _PixelShuffleTokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vit_output, skip):
+        ctx.skip, ctx.in_shape = skip, vit_output.shape
+        return pixel_shuffle_tokens_launch(vit_output, skip)
+
+    @staticmethod
+    def backward(ctx, dy):                          # the permutation run backwards, zeros for the skipped tokens
+        n, t, c = ctx.in_shape
+        side = int(round(math.sqrt(t - ctx.skip)))
+        g = dy.reshape(n, side // 2, side // 2, 4 * c).permute(0, 2, 1, 3).reshape(n, side // 2, side, 2 * c)
+        g = g.permute(0, 2, 1, 3).reshape(n, side * side, c)
+        dx = torch.zeros(ctx.in_shape, dtype=dy.dtype, device=dy.device)
+        dx[:, ctx.skip:] = g
+        return dx, None
+
+
 def pixel_shuffle_tokens(vit_output: torch.Tensor, skip: int = 1) -> torch.Tensor:
+    """Differentiable form of ``pixel_shuffle_tokens_launch``."""
+    if torch.is_grad_enabled() and vit_output.requires_grad:
+        return _PixelShuffleTokens.apply(vit_output, skip)
+    return pixel_shuffle_tokens_launch(vit_output, skip)
+
+
+def pixel_shuffle_tokens_launch(vit_output: torch.Tensor, skip: int = 1) -> torch.Tensor:
     """[N, skip + side*side, C] bf16 -> [N, (side/2)^2, 4C]: class-token drop + pixel
     shuffle with scale 0.5 (lcvlm_modellink/pretrain_lcvlm.py:463-470, 546-556)."""
     _require_gpu(vit_output)
@@ -455,8 +479,7 @@ def bias_gelu(x: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor
     return bias_gelu_launch(x, bias)
 
 
-def bias_scale_residual(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
-    """residual + (x + bias) * ls with per-column bias / ls, all [..., h] contiguous bf16."""
+def bias_scale_residual_launch(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
     _bf16_2d(x, "bias_scale_residual")
     x, residual = x.contiguous(), residual.contiguous()
     if residual.shape != x.shape:
@@ -466,6 +489,36 @@ def bias_scale_residual(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Te
     check(_lib.lib().lv_bias_scale_residual(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(ls.contiguous()),
                                             _ptr(residual), _ptr(out), x.numel() // h, h, _stream()), "lv_bias_scale_residual")
     return out
+
+
+class _BiasScaleResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, ls, residual):
+        ctx.save_for_backward(x, bias, ls)
+        return bias_scale_residual_launch(x, bias, ls, residual)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, bias, ls = ctx.saved_tensors
+        h = x.shape[-1]
+        d2 = dout.reshape(-1, h)
+        dx = (d2 * ls).view(x.shape) if ctx.needs_input_grad[0] else None
+        col = d2.sum(0, dtype=torch.float32)
+        dbias = (col * ls.float()).to(bias.dtype) if (bias is not None and ctx.needs_input_grad[1]) else None
+        dls = None
+        if ctx.needs_input_grad[2]:
+            dls = (d2.float() * x.reshape(-1, h).float()).sum(0)
+            if bias is not None:
+                dls = dls + col * bias.float()
+            dls = dls.to(ls.dtype)
+        return dx, dbias, dls, (dout if ctx.needs_input_grad[3] else None)
+
+
+def bias_scale_residual(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    """residual + (x + bias) * ls with per-column bias / ls, all [..., h] contiguous bf16; differentiable."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, bias, ls, residual)):
+        return _BiasScaleResidual.apply(x, bias, ls, residual)
+    return bias_scale_residual_launch(x, bias, ls, residual)
 
 
 def patchify(img: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
@@ -478,8 +531,7 @@ def patchify(img: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
     return out
 
 
-def embed_tokens(proj: torch.Tensor, conv_bias: torch.Tensor, class_token: torch.Tensor | None, pos_emb: torch.Tensor) -> torch.Tensor:
-    """proj [n, n_patches, h] -> tokens [n_class + n_patches, n, h] = cat(class_token, proj + conv_bias) + pos_emb."""
+def embed_tokens_launch(proj, conv_bias, class_token, pos_emb) -> torch.Tensor:
     _bf16_2d(proj, "embed_tokens")
     proj = proj.contiguous()
     n, npatch, h = proj.shape
@@ -491,3 +543,31 @@ def embed_tokens(proj: torch.Tensor, conv_bias: torch.Tensor, class_token: torch
                                      _ptr(class_token.reshape(-1, h).contiguous() if class_token is not None else None),
                                      _ptr(pos_emb.contiguous()), _ptr(out), n, npatch, ncls, h, _stream()), "lv_embed_tokens")
     return out
+
+
+class _EmbedTokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj, conv_bias, class_token, pos_emb):
+        ctx.shapes = (proj.shape, None if class_token is None else class_token.shape, pos_emb.shape)
+        ctx.dtypes = (conv_bias.dtype, None if class_token is None else class_token.dtype, pos_emb.dtype)
+        return embed_tokens_launch(proj, conv_bias, class_token, pos_emb)
+
+    @staticmethod
+    def backward(ctx, dtok):                      # dtok [s, n, h]
+        (n, npatch, h), cls_shape, pos_shape = ctx.shapes
+        ncls = dtok.shape[0] - npatch
+        dproj = dtok[ncls:].transpose(0, 1).contiguous()
+        per_pos = dtok.sum(1, dtype=torch.float32)             # [s, h]
+        dbias = per_pos[ncls:].sum(0).to(ctx.dtypes[0])
+        dcls = per_pos[:ncls].reshape(cls_shape).to(ctx.dtypes[1]) if cls_shape is not None else None
+        dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dtok.device)
+        dpos[: dtok.shape[0]] = per_pos
+        return dproj, dbias, dcls, dpos.to(ctx.dtypes[2])
+
+
+def embed_tokens(proj: torch.Tensor, conv_bias: torch.Tensor, class_token: torch.Tensor | None, pos_emb: torch.Tensor) -> torch.Tensor:
+    """proj [n, n_patches, h] -> tokens [n_class + n_patches, n, h] = cat(class_token, proj + conv_bias) + pos_emb;
+    differentiable in all four."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (proj, conv_bias, class_token, pos_emb)):
+        return _EmbedTokens.apply(proj, conv_bias, class_token, pos_emb)
+    return embed_tokens_launch(proj, conv_bias, class_token, pos_emb)

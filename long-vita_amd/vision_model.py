@@ -8,9 +8,9 @@ shipped script uses: ``--vision-model-type intern_300m --vision-downsample-ratio
 --vision-projector-pre-norm``.  Parameter names follow the reference (``vit.*``, ``pre_proj_layernorm.*``,
 ``vision_projection.encoder.linear_fc1/linear_fc2.weight``).
 
-The tower is forward-only here (``--vision-model-freeze``, as the long-context stages and the servers run it);
-the projector trains in every stage, so its LayerNorm and GELU are differentiable (HIP forward and backward
-kernels), the two GEMMs go through the BLAS library under torch autograd.
+The tower runs without a graph under ``--vision-model-freeze`` (the long-context stages and the servers) and is
+differentiable otherwise (stage 2); the projector trains in every stage.  LayerNorm, GELU and attention have HIP
+forward and backward kernels, the GEMMs go through the BLAS library under torch autograd.
 """
 from __future__ import annotations
 
@@ -57,8 +57,6 @@ class MegatronVisionModel(torch.nn.Module):
                  vision_context_parallel: bool = False):
         super().__init__()
         vit_config = vit_config or InternViTConfig()
-        if not vision_model_freeze:
-            raise NotImplementedError("the tower is built forward-only: run it with vision_model_freeze=True")
         if vision_downsample_ratio != 0.5:
             raise NotImplementedError("only vision_downsample_ratio=0.5 is built")
         self.vision_context_parallel = vision_context_parallel
@@ -66,7 +64,7 @@ class MegatronVisionModel(torch.nn.Module):
         self.add_class_token = vit_config.add_class_token
         self.vision_model_freeze = vision_model_freeze
         self.vision_projector_freeze = vision_projector_freeze
-        self.vit = InternViTModel(vit_config, vision_context_parallel=vision_context_parallel)
+        self.vit = InternViTModel(vit_config, vision_context_parallel=vision_context_parallel, freeze=vision_model_freeze)
         self.vision_seq_length = self.vit.seq_length
         self.image_token_length = int(self.vit.num_patches * vision_downsample_ratio ** 2)
         proj_input_size = vit_config.hidden_size * int(1 / vision_downsample_ratio) ** 2
@@ -82,10 +80,9 @@ class MegatronVisionModel(torch.nn.Module):
 
     def forward_once(self, images, attention_mask=None):
         """pretrain_lcvlm.py:453-494: [n, 3, H, W] -> [n, image_token_length, hidden]."""
-        with torch.no_grad():
-            vit_output = self.vit(images, attention_mask)
-            # class-token drop, [n, 32, 32, c] view and pixel_shuffle(0.5), flattened: one pass over the data
-            vit_output = ops.pixel_shuffle_tokens(vit_output, skip=1 if self.add_class_token else 0)
+        vit_output = self.vit(images, attention_mask)           # without a graph when the tower is frozen
+        # class-token drop, [n, 32, 32, c] view and pixel_shuffle(0.5), flattened: one pass over the data
+        vit_output = ops.pixel_shuffle_tokens(vit_output, skip=1 if self.add_class_token else 0)
         if self.vision_projector_freeze:
             with torch.no_grad():
                 return self.forward_projection(vit_output)
