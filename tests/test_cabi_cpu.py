@@ -92,3 +92,44 @@ def test_ops_refuse_cpu_tensors():
     q = torch.zeros(4, 1, 128, dtype=torch.bfloat16)
     with pytest.raises(_lib.LvAttnError):
         ops.varlen_attention(q, q, q, [0, 4])
+
+
+def test_argument_validation_rejects_before_any_launch():
+    """Entry points check their arguments on the host and return LV_EINVAL with a message; none of these calls
+    reaches a kernel launch (the pointers are never dereferenced), so they run without a GPU."""
+    from long_vita_amd import _lib
+    L = _lib.lib()
+    buf = (C.c_char * 4096)()
+    p = C.addressof(buf)          # 16-byte alignment is not guaranteed by ctypes: align by hand
+    p = (p + 255) & ~255
+    err = lambda: L.lvattn_last_error().decode()
+    f = C.c_float(0.1)
+    # head dim 96
+    rc = L.lvattn_fwd(p, p, p, p, p, p, 1, 64, 64, 4, 2, 96, 1024, 96, 512, 96, 512, 96, 1024, 96, 64, f, 1, None)
+    assert rc != 0 and "head dim" in err()
+    # 5 query heads over 2 KV heads
+    rc = L.lvattn_fwd(p, p, p, p, p, p, 1, 64, 64, 5, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None)
+    assert rc != 0 and "multiple" in err()
+    # misaligned q
+    rc = L.lvattn_fwd(p + 2, p, p, p, p, p, 1, 64, 64, 4, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None)
+    assert rc != 0 and "aligned" in err()
+    # lse row shorter than the rows
+    rc = L.lvattn_fwd(p, p, p, p, p, p, 1, 64, 64, 4, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 32, f, 1, None)
+    assert rc != 0 and "lse_stride" in err()
+    # zero work items: accepted, nothing launched
+    assert L.lvattn_fwd(p, p, p, p, p, p, 0, 64, 64, 4, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None) == 0
+    # incremental attention: 33 query heads per KV head, empty cache, short workspace
+    ws = L.lvattn_decode_workspace_bytes(1, 40, 8, 128)
+    assert ws > 0 and L.lvattn_decode_workspace_bytes(1, 5, 2, 128) == 0
+    rc = L.lvattn_decode(p, p, p, p, None, p, ws, 1, 100, 66, 2, 128, 8448, 128, 25600, 256, 128, 25600, 256, 128, 8448, 128, f, 0, None)
+    assert rc != 0 and "at most 32" in err()
+    rc = L.lvattn_decode(p, p, p, p, None, p, ws, 1, 0, 40, 8, 128, 5120, 128, 1024, 1024, 128, 1024, 1024, 128, 5120, 128, f, 0, None)
+    assert rc != 0 and "k_len" in err()
+    rc = L.lvattn_decode(p, p, p, p, None, p, 16, 1, 100000, 40, 8, 128, 5120, 128, 1024, 1024, 128, 1024, 1024, 128, 5120, 128, f, 0, None)
+    assert rc != 0 and "workspace" in err()
+    # LayerNorm backward: rows wider than it supports
+    rc = L.lv_layernorm_bwd(p, p, p, p, p, p, 1 << 20, 4, 8192, 8192, 8192, 8192, C.c_float(1e-5), None)
+    assert rc != 0 and "4096" in err()
+    # unknown kernel name
+    assert L.lvattn_select_fwd_kernel(b"nope") != 0 and "unknown forward kernel" in err()
+    assert L.lvattn_select_fwd_kernel(b"default") == 0
