@@ -238,3 +238,25 @@ def test_every_forward_kernel_variant(kernel):
         _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
     with pytest.raises(_lib.LvAttnError):
         _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"no-such-kernel"), "select")
+
+
+def test_full_size_backward_invariants_cfg3():
+    """Backward at the 131,072-token / 40-8-head size of the forward+backward measurements, checked through identities
+    that hold at any size: rows of P sum to one, so  sum_j dV[j] = sum over the group's heads and all rows of dO;
+    dQ = scale dS K and dK = scale dS^T Q, so  sum_i <q_i, dq_i> (over the group's heads) = sum_j <k_j, dk_j>."""
+    from long_vita_amd import ops
+    S, Hq, Hkv, D = 131072, 40, 8, 128
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(3)
+    rnd = lambda *shape: (torch.randn(*shape, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    q, k, v, do = rnd(S, Hq, D).requires_grad_(True), rnd(S, Hkv, D).requires_grad_(True), rnd(S, Hkv, D).requires_grad_(True), rnd(S, Hq, D)
+    out, _ = ops.varlen_attention(q, k, v, [0, S], A.default_scale(D), True)
+    out.backward(do)
+    torch.cuda.synchronize()
+    rep = Hq // Hkv
+    dv_sum = v.grad.double().sum(0)                                            # [Hkv, D]
+    do_sum = do.double().sum(0).reshape(Hkv, rep, D).sum(1)
+    assert (dv_sum - do_sum).abs().max().item() <= 1e-2 * do_sum.abs().max().item()
+    qdq = (q.detach().double() * q.grad.double()).sum((0, 2)).reshape(Hkv, rep).sum(1)   # [Hkv]
+    kdk = (k.detach().double() * k.grad.double()).sum((0, 2))
+    assert (qdq - kdk).abs().max().item() <= 2e-2 * max(qdq.abs().max().item(), kdk.abs().max().item())
