@@ -103,3 +103,54 @@ def test_ring_two_processes_one_gpu_torch_distributed(tmp_path):
     for name, ref, H in (("out", ref_o, Hq), ("dq", rdq, Hq), ("dk", rdk, Hkv), ("dv", rdv, Hkv)):
         got = unzigzag([r[name][:, 0] for r in res], world).reshape(S, H, D)
         assert rel(got, ref) <= REL_TOL, name
+
+
+class _FeedComm:
+    """Stands in for the ring's transport for ONE rank: each exchange delivers, on a side stream, the K / V block the
+    rank would receive at that step (the zig-zag shard of rank r - step - 1), taken from the whole K / V."""
+
+    def __init__(self, rank, cp, k_all, v_all):
+        self.rank, self.cp, self.k_all, self.v_all = rank, cp, k_all, v_all
+        self.step = 0
+        self.stream = torch.cuda.Stream()
+
+    def exchange(self, send_bufs, recv_bufs, dst, src):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        src_rank = (self.rank - self.step - 1) % self.cp
+        self.step += 1
+        with torch.cuda.stream(self.stream):
+            recv_bufs[0][0].copy_(zigzag_local(self.k_all, self.cp, src_rank))
+            recv_bufs[0][1].copy_(zigzag_local(self.v_all, self.cp, src_rank))
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return done
+
+    def wait(self, handle):
+        torch.cuda.current_stream().wait_event(handle)
+
+
+def test_full_size_ring_rank_equals_single_launch_1m():
+    """The 1,048,576-token, CP = 8 case of the scaling runs: what two of the ranks compute over their eight ring steps
+    (block kernels on the three kinds of rectangle + log-sum-exp merges) against the rows of ONE causal launch over
+    the whole context."""
+    from long_vita_amd import ops
+    from long_vita_amd.ring_context_parallel import RingAttention
+    S, Hq, Hkv, D, cp = 1048576, 40, 8, 128, 8
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *shape: (torch.randn(*shape, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    q, k, v = rnd(S, Hq, D), rnd(S, Hkv, D), rnd(S, Hkv, D)
+    scale = A.default_scale(D)
+    whole, whole_lse = ops.varlen_attention(q, k, v, [0, S], scale, True)
+    s_loc = S // cp
+    for r in (0, 5):
+        eng = RingAttention(None, cp, r, causal=True, comm=_FeedComm(r, cp, k, v))
+        ql, kl, vl = (zigzag_local(x, cp, r).reshape(s_loc, 1, -1) for x in (q, k, v))
+        out, lse = eng.forward(ql, kl, vl, Hq, scale, return_state=True)
+        torch.cuda.synchronize()
+        want = zigzag_local(whole, cp, r).float()
+        err = (out.reshape(s_loc, Hq, D).float() - want).abs().max().item()
+        assert err <= REL_TOL * want.abs().max().item(), (r, err)
+        want_lse = zigzag_local(whole_lse.t(), cp, r).t()
+        assert (lse - want_lse).abs().max().item() <= LSE_TOL, r
+        del eng, out, lse, want
