@@ -347,6 +347,9 @@ def main():
             gbs = hbm_bytes_per_step / mean_kernel_s / 1e9
             res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                "traffic": None, "note": "algorithmic bytes per step / mean device time per step"}
+            if wl == "decode" and not args.seq and not args.heads:
+                per_call, traffic_note = profiled_traffic("r01_decode_pmc_summary.json", "lv_decode_kernel<128>")
+                res["roofline"]["traffic"] = per_call      # per launch of the dominant kernel (16 launches per step)
         if traffic_note:
             res["roofline"]["traffic_note"] = traffic_note
         if not args.no_cpu_baseline and wl == "prefill_1m":
