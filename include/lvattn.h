@@ -95,6 +95,9 @@ int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* ls
  * process ("default", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
  * is read on first use otherwise).  Not thread-safe against concurrent launches. */
 int lvattn_select_fwd_kernel(const char* name);
+/* The same for the backward: dq in {"default", "pp", "lockstep"}, dkdv in {"default", "rs" (role-split, two units per
+ * iteration), "rs1" (one unit), "single"} -- LVATTN_DQ_KERNEL / LVATTN_DKDV_KERNEL / LVATTN_DKDV_UNITS otherwise. */
+int lvattn_select_bwd_kernels(const char* dq, const char* dkdv);
 
 /* ---- incremental attention over a KV cache -------------------------------------
  * Replaces torch_npu.npu_incre_flash_attention as called with --use-kv-cache

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "lv_scatter_rows": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp]),
     "lv_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "lvattn_select_fwd_kernel": (_int, [C.c_char_p]),
+    "lvattn_select_bwd_kernels": (_int, [C.c_char_p, C.c_char_p]),
     "lvattn_decode_workspace_bytes": (_i64, [_int, _int, _int, _int]),
     "lvattn_decode": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int,
                              _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _vp]),

@@ -622,22 +622,28 @@ __global__ __launch_bounds__(512, 2) void lv_bwd_dq_kernel(BwdParams p) {
 
 // dQ kernel choice: the ping-pong kernel (attn_bwd_dq_pp.hip) unless the environment variable
 // LVATTN_DQ_KERNEL=lockstep asks for the one in this file.
+static int g_dq_kernel = -1, g_dkdv_kernel = -1;   // -1: environment not read yet; 0 default kernel, 1 the one in this file
 static bool dq_pingpong() {
-    static bool v = [] {
+    if (g_dq_kernel < 0) {
         const char* e = getenv("LVATTN_DQ_KERNEL");
-        return !(e && !strcmp(e, "lockstep"));
-    }();
-    return v;
+        g_dq_kernel = (e && !strcmp(e, "lockstep")) ? 1 : 0;
+    }
+    return g_dq_kernel == 0;
 }
 
 // dK/dV kernel choice: the role-split kernel (attn_bwd_dkdv_rs.hip) unless the environment variable
 // LVATTN_DKDV_KERNEL=single asks for the one-wave-per-SIMD kernel in this file.
 static bool dkdv_role_split() {
-    static bool v = [] {
+    if (g_dkdv_kernel < 0) {
         const char* e = getenv("LVATTN_DKDV_KERNEL");
-        return !(e && !strcmp(e, "single"));
-    }();
-    return v;
+        g_dkdv_kernel = (e && !strcmp(e, "single")) ? 1 : 0;
+    }
+    return g_dkdv_kernel == 0;
+}
+// run-time override of the two choices above: 0 default, 1 the kernel in this file, < 0 leave as it is
+void lv_select_bwd_kernels(int dq, int dkdv) {
+    if (dq >= 0) g_dq_kernel = dq;
+    if (dkdv >= 0) g_dkdv_kernel = dkdv;
 }
 
 template <int D>

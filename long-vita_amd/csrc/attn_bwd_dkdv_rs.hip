@@ -375,13 +375,15 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     }
 }
 
-static int rs_units() {   // LVATTN_DKDV_UNITS=1|2: 32-row units per iteration (read once)
-    static const int n = [] {
+static int g_rs_units = 0;   // 0: environment not read yet
+static int rs_units() {      // LVATTN_DKDV_UNITS=1|2: 32-row units per iteration
+    if (g_rs_units == 0) {
         const char* e = getenv("LVATTN_DKDV_UNITS");
-        return (e && e[0] == '1') ? 1 : 2;
-    }();
-    return n;
+        g_rs_units = (e && e[0] == '1') ? 1 : 2;
+    }
+    return g_rs_units;
 }
+void lv_select_rs_units(int n) { g_rs_units = (n == 1) ? 1 : 2; }
 
 template <int D, int NSL>
 static void launch_rs(const BwdParams& p, int causal, int accum, hipStream_t stream) {

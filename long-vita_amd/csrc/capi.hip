@@ -40,6 +40,21 @@ extern "C" int lvattn_select_fwd_kernel(const char* name) {
     g_fwd_kernel = fwd_kernel_code(name);
     return LV_OK;
 }
+extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
+    int a = 0, b = 0, units = 2;
+    if (dq && dq[0] && strcmp(dq, "default") && strcmp(dq, "pp")) {
+        if (strcmp(dq, "lockstep")) return fail(LV_EINVAL, "unknown dQ kernel '%s' (default, pp, lockstep)", dq);
+        a = 1;
+    }
+    if (dkdv && dkdv[0] && strcmp(dkdv, "default") && strcmp(dkdv, "rs")) {
+        if (!strcmp(dkdv, "single")) b = 1;
+        else if (!strcmp(dkdv, "rs1")) units = 1;
+        else return fail(LV_EINVAL, "unknown dK/dV kernel '%s' (default, rs, rs1, single)", dkdv);
+    }
+    lv_select_bwd_kernels(a, b);
+    lv_select_rs_units(units);
+    return LV_OK;
+}
 static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
 static bool fwd_pingpong(int d) {
     const int o = fwd_kernel_override();

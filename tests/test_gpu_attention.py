@@ -260,3 +260,26 @@ def test_full_size_backward_invariants_cfg3():
     qdq = (q.detach().double() * q.grad.double()).sum((0, 2)).reshape(Hkv, rep).sum(1)   # [Hkv]
     kdk = (k.detach().double() * k.grad.double()).sum((0, 2))
     assert (qdq - kdk).abs().max().item() <= 2e-2 * max(qdq.abs().max().item(), kdk.abs().max().item())
+
+
+@pytest.mark.parametrize("dq,dkdv", [("lockstep", "single"), ("pp", "rs1"), ("pp", "rs")])
+def test_every_backward_kernel_variant(dq, dkdv):
+    """The backward kernels that are not the default stay selectable and correct."""
+    from long_vita_amd import ops, _lib
+    _lib.check(_lib.lib().lvattn_select_bwd_kernels(dq.encode(), dkdv.encode()), "select")
+    try:
+        for cu, Hq, Hkv, D, causal in [([0, 100, 356, 357, 700, 1000], 10, 2, 128, True), ([0, 200, 520], 4, 2, 128, False),
+                                       ([0, 130, 450], 4, 2, 64, True)]:
+            T = cu[-1]
+            q, k, v = make_qkv(T, Hq, Hkv, D, seed=T + D)
+            g = torch.Generator().manual_seed(5)
+            do = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+            scale = A.default_scale(D)
+            rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale, causal)
+            qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+            out, _ = ops.varlen_attention(qc, kc, vc, cu, scale, causal)
+            out.backward(do.cuda())
+            torch.cuda.synchronize()
+            assert rel_err(qc.grad, rdq) <= REL_TOL and rel_err(kc.grad, rdk) <= REL_TOL and rel_err(vc.grad, rdv) <= REL_TOL, (dq, dkdv, cu)
+    finally:
+        _lib.check(_lib.lib().lvattn_select_bwd_kernels(b"default", b"default"), "select")
