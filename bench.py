@@ -273,26 +273,29 @@ def main():
                   "seq_len": S, "q_heads": HQ, "kv_heads": HKV, "head_dim": D}
         scaling = "weak"
     elif wl == "vit_tower":  # the whole frozen InternViT-300M encoder on 64 tiles of 448 x 448 (random weights)
-        from long_vita_amd import intern_vit as iv
+        from long_vita_amd import intern_vit as iv, vision_model as vmod
         B = 64
         cfg = iv.InternViTConfig()
         torch.manual_seed(1)
-        tower = iv.InternViTModel(cfg).to(torch.bfloat16).to(dev)
+        vision = vmod.MegatronVisionModel(hidden_size=5120, vit_config=cfg, vision_projector_freeze=True).to(torch.bfloat16).to(dev)
+        tower = vision.vit
         img = rnd(B, 3, cfg.img_h, cfg.img_w)
 
         def step():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tower(img)
+            vision(images=img)      # tower -> class-token drop + pixel shuffle (256 tokens per frame) -> projector
             e1.record()
             return e0, e1
         Sv, hd, ffn = tower.seq_length, cfg.hidden_size, cfg.ffn_hidden_size
         tokens_per_step = B * Sv
         per_token = 2.0 * hd * (4 * hd + 2 * ffn) + 4.0 * Sv * hd
-        flops_per_step = cfg.num_layers * B * Sv * per_token + B * tower.num_patches * 2.0 * 3 * cfg.patch_dim ** 2 * hd
+        flops_per_step = (cfg.num_layers * B * Sv * per_token + B * tower.num_patches * 2.0 * 3 * cfg.patch_dim ** 2 * hd
+                          + B * 256 * 2.0 * (4 * hd * hd + hd * 5120))
         flops_per_gpu_step = flops_per_step
-        config = {"workload": "vit_tower: InternViT-300M encoder forward (24 layers, GEMMs + attention + fused elementwise), 64 tiles of 448x448",
-                  "tiles": B, "seq_len": Sv, "hidden": hd, "layers": cfg.num_layers}
+        config = {"workload": "vit_tower: InternViT-300M encoder on 64 frames of 448x448 (24 layers: GEMMs + attention + fused "
+                              "elementwise), pixel shuffle to 256 tokens per frame, projector to 5120",
+                  "frames": B, "seq_len": Sv, "hidden": hd, "layers": cfg.num_layers}
         scaling = "weak"
     else:  # cfg2_vit: 24 layers x 64 frames x 16 heads x 1025 tokens, d=64, non-causal
         B, H, Sv, Dv, layers = 64, 16, 1025, 64, 24
