@@ -13,7 +13,6 @@ decomposition max = log-sum-exp, sum = 1 (lse = max + ln(sum) as in the NPU op).
 """
 from __future__ import annotations
 
-import math
 
 import torch
 

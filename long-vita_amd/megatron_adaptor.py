@@ -8,7 +8,8 @@ Megatron / MindSpeed ones when those packages are importable."""
 from __future__ import annotations
 
 from . import state
-from .core_attention import (do_ring_context_parallel, dot_product_attention_forward_wrapper, flash_attention_forward)
+from .core_attention import (do_ring_context_parallel, dot_product_attention_forward_wrapper,  # noqa: F401  (the wrapper is re-exported)
+                             flash_attention_forward)
 from .ring_context_parallel import ringattn_context_parallel
 from .rotary_pos_embedding import RotaryEmbedding, apply_rotary_pos_emb
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LV_BWD_BLOCK_N, LV_DESC_INTS, LV_FWD_BLOCK_M, LvAttnError, check
+from ._lib import LV_BWD_BLOCK_N, LV_DESC_INTS, LvAttnError, check
 
 _I32P = C.POINTER(C.c_int32)
 
