@@ -13,8 +13,9 @@ flash_attention_forward', flash_attention_forward)`` (megatron_adaptor.py:11-13)
 can point at this module unchanged.  Differences, on purpose:
   * the global ``args`` object is never written (the reference mutates
     args.sparse_mode / shape_order / pre_tockens as a side effect, :329,383,389,406);
-  * packed segments + context parallelism raises NotImplementedError instead of
-    the reference's latent TypeError (:342-343 passes a keyword :36 does not take);
+  * packed segments + context parallelism (:339-343) calls the ring WITHOUT the keyword the reference passes
+    and do_ring_context_parallel does not take (a latent TypeError there); the ring reads the segments from
+    get_actual_seq_len() as :38 does and keeps attention inside them;
   * alibi / pse and sliding window are outside this path and raise NotImplementedError;
   * the kv-cache prompt op always applies the causal mask aligned to the end of the keys (the
     reference forwards args.sparse_mode and its stored mask, which describe the same thing).
@@ -83,8 +84,11 @@ def flash_attention_forward(self, query, key, value, attention_mask, attn_mask_t
         assert actual_seq_len is not None
         scale = _softmax_scale(self)
         if args.context_parallel_size > 1 and args.context_parallel_algo in _RING_ALGOS:
-            raise NotImplementedError("packed segments with context parallelism: the reference path fails here as well "
-                                      "(do_ring_context_parallel takes no actual_seq_len)")
+            # :339-343.  The reference passes `actual_seq_len=` to do_ring_context_parallel, which does not take it
+            # (:36) and reads the same list from get_actual_seq_len() itself (:38): called without it, the ring gets
+            # the segments the way the call was meant to deliver them.
+            q, k, v = (x.reshape(x.shape[0], x.shape[1], -1) for x in (query, key, value))
+            return do_ring_context_parallel(q, k, v, head_num=n_head, softmax_scale=scale, attn_mask=None)
         # 's b h d -> (b s) h d' (:345): a view when b == 1, as in every shipped script
         to_t = lambda x: x.permute(1, 0, 2, 3).reshape(batch_size * x.shape[0], x.shape[2], head_dim)
         out = npu_fusion_attention(to_t(query), to_t(key), to_t(value), n_head, "TND", pse=None, padding_mask=None,

@@ -109,6 +109,22 @@ def rect_blocks_on_device(q_row0, q_len, k_row0, k_len, causal, shift, backward,
         build_rect_blocks_host(q_row0, q_len, k_row0, k_len, causal, shift, backward)).to(device))
 
 
+def rects_blocks_on_device(rects, backward: bool, device) -> torch.Tensor:
+    """Descriptors for several rectangles of one launch: ``rects`` = tuples (q_row0, q_len, k_row0, k_len, shift), all
+    causal with their own shift (key j of the rectangle visible to its row i iff j <= i + shift; a shift >= k_len makes
+    the rectangle dense).  The rectangles of one launch must not share query rows (forward, dQ) or key rows (dK/dV).
+    Heaviest work items first, as for a single rectangle."""
+    rects = tuple(tuple(int(x) for x in r) for r in rects)
+    key = ("rects", rects, bool(backward), str(device))
+
+    def build():
+        parts = [build_rect_blocks_host(q0, ql, k0, kl, True, sh, backward) for q0, ql, k0, kl, sh in rects]
+        d = np.concatenate(parts) if parts else np.zeros((0, LV_DESC_INTS), dtype=np.int32)
+        order = np.argsort(-(d[:, 1].astype(np.int64) * d[:, 3].astype(np.int64)), kind="stable")
+        return torch.from_numpy(np.ascontiguousarray(d[order])).to(device)
+    return _blocks.get(key, build)
+
+
 # ---------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------

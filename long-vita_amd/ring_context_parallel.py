@@ -42,6 +42,15 @@ class HipBackend:
         desc = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, False, q3.device)
         self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, causal, out_blk, lse_blk)
 
+    def block_fwd_rects(self, q3, k3, v3, rects, scale, out_blk, lse_blk):
+        desc = self.ops.rects_blocks_on_device(rects, False, q3.device)
+        self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, True, out_blk, lse_blk)
+
+    def block_bwd_rects(self, q3, k3, v3, out3, dout3, lse, delta, rects, scale, dq_acc, dk_acc, dv_acc):
+        desc_q = self.ops.rects_blocks_on_device(rects, False, q3.device)
+        desc_k = self.ops.rects_blocks_on_device(rects, True, q3.device)
+        self.ops.attn_bwd_launch(q3, k3, v3, out3, dout3, lse, desc_q, desc_k, scale, True, dq_acc, dk_acc, dv_acc, delta, True)
+
     def merge(self, out_acc, lse_acc, out_blk, lse_blk, row0, rows):
         self.ops.merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0, rows)
 
@@ -145,9 +154,48 @@ class RingAttention:
             return (0, s_loc), (0, c), False, 0
         return (c, c), (0, s_loc), False, 0
 
+    def segment_rects(self, step: int, s_loc: int, cu_seqlens):
+        """Packed segments under the zig-zag split.  ``cu_seqlens`` are the segment boundaries in GLOBAL token
+        positions ([0, ..., S]).  For ring step ``step`` returns four lists, one per (query chunk, key chunk) pair of
+        this rank's rows against the block of rank ``rank - step``: rectangles (q_row0, q_len, k_row0, k_len, shift)
+        in LOCAL row / key indices, key j visible to row i iff j <= i + shift with shift = global position of the
+        rectangle's first row - that of its first key (the causal rule on global positions; segments never mix).
+        Inside one pair the rectangles share neither query rows nor key rows, and their query ranges abut."""
+        c = s_loc // 2
+        src = (self.rank - step) % self.cp
+        qchunks = ((self.rank * c, 0), ((2 * self.cp - 1 - self.rank) * c, c))      # (global start, local start)
+        kchunks = ((src * c, 0), ((2 * self.cp - 1 - src) * c, c))
+        pairs = []
+        for qg0, ql0 in qchunks:
+            for kg0, kl0 in kchunks:
+                rects = []
+                if kg0 < qg0 + c:   # some key of the chunk is not after every query of the chunk
+                    for s0, s1 in zip(cu_seqlens[:-1], cu_seqlens[1:]):
+                        a0, a1 = max(s0, qg0), min(s1, qg0 + c)
+                        b0, b1 = max(s0, kg0), min(s1, kg0 + c)
+                        if a1 > a0 and b1 > b0 and b0 < a1:
+                            rects.append((ql0 + a0 - qg0, a1 - a0, kl0 + b0 - kg0, b1 - b0, a0 - b0))
+                pairs.append(rects)
+        return pairs
+
+    def _fwd_rects(self, be, q3, k3, v3, rects, scale, out_blk, lse_blk):
+        if hasattr(be, "block_fwd_rects"):
+            be.block_fwd_rects(q3, k3, v3, rects, scale, out_blk, lse_blk)
+        else:
+            for q0, ql, k0, kl, sh in rects:
+                be.block_fwd(q3, k3, v3, (q0, ql), (k0, kl), True, sh, scale, out_blk, lse_blk)
+
+    def _bwd_rects(self, be, q3, k3, v3, out3, dout3, lse, delta, rects, scale, dq_acc, dk_acc, dv_acc):
+        if hasattr(be, "block_bwd_rects"):
+            be.block_bwd_rects(q3, k3, v3, out3, dout3, lse, delta, rects, scale, dq_acc, dk_acc, dv_acc)
+        else:
+            for q0, ql, k0, kl, sh in rects:
+                be.block_bwd(q3, k3, v3, out3, dout3, lse, delta, (q0, ql), (k0, kl), True, sh, scale, dq_acc, dk_acc, dv_acc)
+
     # -- forward -----------------------------------------------------------
-    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False):
-        """q [s, b, Hq*d], k/v [s, b, Hkv*d] (local zig-zag shard) -> out [s, b, Hq*d]."""
+    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False, cu_seqlens=None):
+        """q [s, b, Hq*d], k/v [s, b, Hkv*d] (local zig-zag shard) -> out [s, b, Hq*d].  With ``cu_seqlens`` (global
+        segment boundaries, b == 1) attention stays inside the packed segments."""
         be = self._be()
         s_loc, b, hq_d = q.shape
         d = hq_d // n_heads
@@ -171,9 +219,17 @@ class RingAttention:
             handle = None
             if step + 1 < self.cp:
                 handle = side.exchange([cur], [oth], nxt, prv)
-            qr, kr, causal, shift = self.step_rect(step, s_loc)
-            be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk)
-            be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1])
+            if cu_seqlens is None:
+                qr, kr, causal, shift = self.step_rect(step, s_loc)
+                be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk)
+                be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1])
+            else:
+                for rects in self.segment_rects(step, s_loc, cu_seqlens):
+                    if rects:
+                        self._fwd_rects(be, q3, cur[0], cur[1], rects, scale, out_blk, lse_blk)
+                        lo = min(r[0] for r in rects)
+                        hi = max(r[0] + r[1] for r in rects)
+                        be.merge(out_acc, lse_acc, out_blk, lse_blk, lo, hi - lo)
             if handle is not None:
                 side.wait(handle)
         out = be.finalize(out_acc).reshape(s_loc, b, hq_d)
@@ -182,7 +238,7 @@ class RingAttention:
         return out
 
     # -- backward ----------------------------------------------------------
-    def backward(self, q, k, v, out, lse, dout, n_heads: int, scale: float | None = None):
+    def backward(self, q, k, v, out, lse, dout, n_heads: int, scale: float | None = None, cu_seqlens=None):
         """Gradients (dq, dk, dv) in the layouts/dtypes of q, k, v."""
         be = self._be()
         s_loc, b, hq_d = q.shape
@@ -213,9 +269,14 @@ class RingAttention:
             handle = None
             if step + 1 < self.cp:
                 handle = side.exchange([cur], [oth], nxt, prv)   # K/V travels ahead of the math
-            qr, kr, causal, shift = self.step_rect(step, s_loc)
             dloc.zero_()
-            be.block_bwd(q3, cur[0], cur[1], out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dloc[0], dloc[1])
+            if cu_seqlens is None:
+                qr, kr, causal, shift = self.step_rect(step, s_loc)
+                be.block_bwd(q3, cur[0], cur[1], out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dloc[0], dloc[1])
+            else:
+                for rects in self.segment_rects(step, s_loc, cu_seqlens):   # one launch per chunk pair: no shared rows
+                    if rects:
+                        self._bwd_rects(be, q3, cur[0], cur[1], out3, dout3, lse, delta, rects, scale, dq_acc, dloc[0], dloc[1])
             if handle is not None:
                 side.wait(handle)
             if self.cp > 1:
@@ -240,17 +301,17 @@ class RingAttention:
 
 class _RingAttnFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, engine, n_heads, scale):
-        out, lse = engine.forward(q, k, v, n_heads, scale, return_state=True)
+    def forward(ctx, q, k, v, engine, n_heads, scale, cu_seqlens=None):
+        out, lse = engine.forward(q, k, v, n_heads, scale, return_state=True, cu_seqlens=cu_seqlens)
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.engine, ctx.n_heads, ctx.scale = engine, n_heads, scale
+        ctx.engine, ctx.n_heads, ctx.scale, ctx.cu_seqlens = engine, n_heads, scale, cu_seqlens
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = ctx.engine.backward(q, k, v, out, lse, dout.contiguous(), ctx.n_heads, ctx.scale)
-        return dq, dk, dv, None, None, None
+        dq, dk, dv = ctx.engine.backward(q, k, v, out, lse, dout.contiguous(), ctx.n_heads, ctx.scale, cu_seqlens=ctx.cu_seqlens)
+        return dq, dk, dv, None, None, None, None
 
 
 _engines: dict = {}
@@ -268,8 +329,19 @@ def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask
         raise NotImplementedError("attention dropout is not supported on the ring path (the shipped scripts use 0)")
     if cp_para.get("pse") is not None:
         raise NotImplementedError("pse / alibi is not supported on the ring path")
-    if actual_seq_qlen is not None and cp_para.get("causal", True) is False:
-        raise NotImplementedError("packed variable-length segments with context parallelism are not supported")
+    cu_seqlens = None
+    if actual_seq_qlen is not None:
+        # packed segments: cumulative END offsets over the WHOLE sequence (before the split over the ranks), as the
+        # data pipeline sets them (lcvlm_modellink/training/utils.py:671-672)
+        if cp_para.get("causal", True) is False:
+            raise NotImplementedError("packed segments with a non-causal ring are not supported")
+        if actual_seq_kvlen is not None and list(actual_seq_kvlen) != list(actual_seq_qlen):
+            raise NotImplementedError("different q / kv segmentations are not supported")
+        if q.shape[1] != 1:
+            raise NotImplementedError("packed segments on the ring need micro-batch 1 (as every shipped script uses)")
+        cu_seqlens = (0,) + tuple(int(x) for x in actual_seq_qlen)
+        if cu_seqlens[-1] != q.shape[0] * int(cp_para["cp_size"]):
+            raise ValueError(f"actual_seq_len ends at {cu_seqlens[-1]}, the sequence has {q.shape[0] * int(cp_para['cp_size'])} tokens")
     cp_size = int(cp_para["cp_size"])
     rank = int(cp_para["rank"])
     group = cp_para.get("cp_group")
@@ -281,7 +353,7 @@ def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask
         _engines[key] = eng
     d = q.shape[-1] // n
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
-    return _RingAttnFunction.apply(q, k, v, eng, n, float(scale))
+    return _RingAttnFunction.apply(q, k, v, eng, n, float(scale), cu_seqlens)
 
 
 def merge_partial_attention(outs: torch.Tensor, lses: torch.Tensor) -> torch.Tensor:

@@ -154,3 +154,38 @@ def test_full_size_ring_rank_equals_single_launch_1m():
         want_lse = zigzag_local(whole_lse.t(), cp, r).t()
         assert (lse - want_lse).abs().max().item() <= LSE_TOL, r
         del eng, out, lse, want
+
+
+@pytest.mark.parametrize("cp,cu", [(2, [0, 300, 301, 1500, 2048]), (4, [0, 700, 2100, 2101, 3900, 4096]), (8, [0, 4096])])
+def test_ring_hip_backend_packed_segments(cp, cu):
+    """Packed segments under the zig-zag split through the HIP kernels (several rectangles per launch, one launch
+    per chunk pair), forward and backward, against the oracle's varlen attention on the whole sequence."""
+    from long_vita_amd.ring_context_parallel import RingAttention
+    S, Hq, Hkv, D = cu[-1], 10, 2, 128
+    g = torch.Generator().manual_seed(100 + cp)
+    q = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    ref_o, ref_lse = A.varlen_attention(q, k, v, cu, scale)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale)
+    fabric = LoopbackFabric(cp)
+    dev = torch.device("cuda", 0)
+
+    def body(r):
+        torch.cuda.set_device(0)
+        eng = RingAttention(None, cp, r, causal=True, comm=LoopbackComm(fabric, r))
+        ql, kl, vl, dl = (zigzag_local(x, cp, r).reshape(S // cp, 1, -1).to(dev) for x in (q, k, v, do))
+        out, lse = eng.forward(ql, kl, vl, Hq, scale, return_state=True, cu_seqlens=tuple(cu))
+        dq, dk, dv = eng.backward(ql, kl, vl, out, lse, dl, Hq, scale, cu_seqlens=tuple(cu))
+        torch.cuda.synchronize()
+        return out[:, 0].cpu(), lse.cpu(), dq[:, 0].cpu(), dk[:, 0].cpu(), dv[:, 0].cpu()
+    res = run_virtual_ranks(cp, body)
+    out = unzigzag([r[0] for r in res], cp).reshape(S, Hq, D)
+    assert rel(out, ref_o) <= REL_TOL
+    lse = unzigzag([r[1].t() for r in res], cp).t()
+    assert np.abs(lse.numpy() - ref_lse).max() <= LSE_TOL
+    for idx, ref, H in ((2, rdq, Hq), (3, rdk, Hkv), (4, rdv, Hkv)):
+        got = unzigzag([r[idx] for r in res], cp).reshape(S, H, D)
+        assert rel(got, ref) <= REL_TOL, idx

@@ -135,6 +135,16 @@ def test_flash_attention_forward_branch_errors():
     with pytest.raises(AssertionError):
         flash_attention_forward(self, q, q, q, None, None, None)
     state.set_actual_seq_len([8])
+    # packed segments + context parallelism go to the ring with the segments from get_actual_seq_len():
+    # their last end must be the length of the WHOLE sequence (local rows x CP)
     state.set_args(state.make_args(reset_attention_mask=True, context_parallel_size=2))
-    with pytest.raises(NotImplementedError):
-        flash_attention_forward(self, q, q, q, None, None, None)
+    state.mpu.initialize(None, 2, 0)
+    try:
+        with pytest.raises(ValueError, match="actual_seq_len ends at 8"):
+            flash_attention_forward(self, q, q, q, None, None, None)
+        state.set_actual_seq_len([5, 16])
+        with pytest.raises(ValueError, match="process group"):   # accepted: the ring starts (and finds no group here)
+            flash_attention_forward(self, q, q, q, None, None, None)
+    finally:
+        state.mpu.initialize(None, 1, 0)
+        state.set_actual_seq_len(None)

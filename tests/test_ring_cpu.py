@@ -74,6 +74,63 @@ def test_ring_virtual_ranks_full_attention(cp):
         np.testing.assert_allclose(got.numpy(), ref, atol=1e-4)
 
 
+@pytest.mark.parametrize("cp,cu", [(2, [0, 5, 6, 30, 64]), (4, [0, 17, 40, 41, 100, 128]), (2, [0, 64]), (4, [0, 16, 32, 48, 64, 80, 96, 112, 128])])
+def test_ring_virtual_ranks_packed_segments(cp, cu):
+    """Packed segments under the zig-zag split (the reference's reset-attention-mask + CP branch): forward and backward
+    over virtual ranks against the oracle's varlen attention with the same global segment boundaries."""
+    from long_vita_amd.ring_context_parallel import RingAttention
+    S, Hq, Hkv, D = cu[-1], 4, 2, 8
+    q, k, v, do = _problem(S, Hq, Hkv, D, seed=7)
+    scale = 0.3
+    ref_o, ref_lse = A.varlen_attention(q, k, v, cu, scale)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale)
+    fabric = LoopbackFabric(cp)
+
+    def body(r):
+        eng = RingAttention(None, cp, r, causal=True, backend=CheckerBackend(), comm=LoopbackComm(fabric, r))
+        ql, kl, vl, dl = (zigzag_local(x, cp, r).reshape(S // cp, 1, -1) for x in (q, k, v, do))
+        out, lse = eng.forward(ql, kl, vl, Hq, scale, return_state=True, cu_seqlens=tuple(cu))
+        dq, dk, dv = eng.backward(ql, kl, vl, out, lse, dl, Hq, scale, cu_seqlens=tuple(cu))
+        return out[:, 0], lse, dq[:, 0], dk[:, 0], dv[:, 0]
+    res = run_virtual_ranks(cp, body)
+    out = unzigzag([r[0] for r in res], cp).reshape(S, Hq, D)
+    np.testing.assert_allclose(out.numpy(), ref_o, atol=2e-5)
+    lse = unzigzag([r[1].t() for r in res], cp).t()
+    np.testing.assert_allclose(lse.numpy(), ref_lse, atol=2e-5)
+    for idx, ref, H in ((2, rdq, Hq), (3, rdk, Hkv), (4, rdv, Hkv)):
+        got = unzigzag([r[idx] for r in res], cp).reshape(S, H, D)
+        np.testing.assert_allclose(got.numpy(), ref, atol=1e-4)
+
+
+def test_segment_rects_cover_each_visible_pair_once():
+    """Every (query, key) pair of the same segment with key <= query lies in exactly one rectangle over all ranks and
+    steps, and no other pair does."""
+    from long_vita_amd.ring_context_parallel import RingAttention
+    for cp, cu in ((2, [0, 5, 6, 30, 64]), (4, [0, 17, 40, 41, 100, 128]), (8, [0, 1, 100, 256])):
+        S = cu[-1]
+        c = S // (2 * cp)
+        seg = np.zeros(S, dtype=int)
+        for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+            seg[a:b] = i
+        want = (seg[:, None] == seg[None, :]) & (np.arange(S)[None, :] <= np.arange(S)[:, None])
+        cover = np.zeros((S, S), dtype=int)
+        for r in range(cp):
+            eng = RingAttention(None, cp, r)
+            gq = np.concatenate([np.arange(r * c, (r + 1) * c), np.arange((2 * cp - 1 - r) * c, (2 * cp - r) * c)])
+            for step in range(cp):
+                src = (r - step) % cp
+                gk = np.concatenate([np.arange(src * c, (src + 1) * c), np.arange((2 * cp - 1 - src) * c, (2 * cp - src) * c)])
+                for rects in eng.segment_rects(step, 2 * c, cu):
+                    rows = [x for q0, ql, *_ in rects for x in range(q0, q0 + ql)]
+                    keys = [x for _, _, k0, kl, _ in rects for x in range(k0, k0 + kl)]
+                    assert len(rows) == len(set(rows)) and len(keys) == len(set(keys))   # one launch: no shared rows
+                    for q0, ql, k0, kl, sh in rects:
+                        for i in range(ql):
+                            for j in range(min(kl, max(0, i + sh + 1))):
+                                cover[gq[q0 + i], gk[k0 + j]] += 1
+        assert (cover == want.astype(int)).all(), (cp, cu)
+
+
 def _gloo_worker(rank, world, port, S, Hq, Hkv, D, scale, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
