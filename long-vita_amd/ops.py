@@ -79,7 +79,7 @@ def build_rect_blocks_host(q_row0: int, q_len: int, k_row0: int, k_len: int, cau
 class _BlockCache:
     """Device copies of descriptor tables, keyed by (segments, causal, direction, device)."""
 
-    def __init__(self, capacity: int = 64):
+    def __init__(self, capacity: int = 1024):   # a packed-segment ring step set is 4 pairs x CP steps x 3 tables
         self.capacity = capacity
         self.store: OrderedDict = OrderedDict()
 
