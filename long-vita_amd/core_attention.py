@@ -29,8 +29,11 @@ from . import state
 from .fusion_attention import npu_fusion_attention, npu_incre_flash_attention, npu_prompt_flash_attention
 from .ring_context_parallel import ringattn_context_parallel
 
-_RING_ALGOS = ("megatron_cp_algo", "hybrid_cp_algo")
-_ALL_CP_ALGOS = _RING_ALGOS + ("adaptive_cp_algo", "hybrid_adaptive_cp_algo")
+_RING_ALGOS = ("megatron_cp_algo",)                       # the one algorithm built here
+# the reference routes these to do_ring_context_parallel too (:339, :374-375); hybrid (ring x Ulysses, on the
+# hybrid-ring subgroup and its own partition, :39-44) and the adaptive ones are not built and raise there
+_REF_RING_BRANCH_ALGOS = ("megatron_cp_algo", "hybrid_cp_algo")
+_ALL_CP_ALGOS = _REF_RING_BRANCH_ALGOS + ("adaptive_cp_algo", "hybrid_adaptive_cp_algo")
 
 
 def _softmax_scale(self):
@@ -45,7 +48,9 @@ def do_ring_context_parallel(q, k, v, head_num, softmax_scale, attn_mask, dropou
     actual_seq_len = state.get_actual_seq_len()
     mpu = state.mpu
     if args.context_parallel_algo not in _RING_ALGOS:
-        raise NotImplementedError(f"context_parallel_algo={args.context_parallel_algo!r}: only the ring algorithm is built")
+        raise NotImplementedError(f"context_parallel_algo={args.context_parallel_algo!r}: only the zig-zag ring "
+                                  "(megatron_cp_algo) is built; hybrid / adaptive context parallelism use other "
+                                  "process groups and another partition of the sequence")
     cp_para = dict(
         causal=args.cp_attention_mask_type == "causal",
         cp_group=mpu.get_context_parallel_group(),
@@ -83,7 +88,7 @@ def flash_attention_forward(self, query, key, value, attention_mask, attn_mask_t
         actual_seq_len = state.get_actual_seq_len()
         assert actual_seq_len is not None
         scale = _softmax_scale(self)
-        if args.context_parallel_size > 1 and args.context_parallel_algo in _RING_ALGOS:
+        if args.context_parallel_size > 1 and args.context_parallel_algo in _REF_RING_BRANCH_ALGOS:
             # :339-343.  The reference passes `actual_seq_len=` to do_ring_context_parallel, which does not take it
             # (:36) and reads the same list from get_actual_seq_len() itself (:38): called without it, the ring gets
             # the segments the way the call was meant to deliver them.

@@ -27,23 +27,24 @@ def zigzag_index(seq_length: int, cp_size: int, cp_rank: int, device=None) -> to
 
 
 def index_of_a_in_b(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """Positions in ``b`` of the elements of ``a`` (all present, ``b`` without duplicates)."""
-    b_indices = torch.where(torch.isin(b, a))[0]
-    b_values = b[b_indices]
-    return b_indices[b_values.argsort()[a.argsort().argsort()]]
+    """For every element of ``a`` its position in ``b`` (every element present, ``b`` free of duplicates):
+    ``b[result] == a``.  One sort of ``b`` and a binary search instead of the reference's three argsorts
+    (lcvlm_modellink/training/utils.py:539-542); the result is the same integer tensor."""
+    sorted_b, where_in_b = torch.sort(b)
+    return where_in_b[torch.searchsorted(sorted_b, a)]
 
 
-def _take_rows(val: torch.Tensor, index: torch.Tensor, dim: int) -> torch.Tensor:
+def _take_rows(val: torch.Tensor, index: torch.Tensor, dim: int, unique: bool = False) -> torch.Tensor:
     if val.is_cuda and dim == 0 and val.dim() >= 2 and (val[0].numel() * val.element_size()) % 4 == 0:
         from . import ops
-        return ops.gather_rows(val, index)
+        return ops.gather_rows(val, index, unique_index=unique)     # differentiable in val
     return val.index_select(dim, index.to(val.device))
 
 
 def zigzag_slice(val: torch.Tensor, cp_size: int, cp_rank: int, seq_dim: int) -> torch.Tensor:
     """utils.py:351-362: view [.., 2CP, s/2CP, ..] -> index_select([r, 2CP-1-r]) -> flatten."""
     idx = zigzag_index(val.shape[seq_dim], cp_size, cp_rank, device=val.device)
-    return _take_rows(val, idx, seq_dim)
+    return _take_rows(val, idx, seq_dim, unique=True)
 
 
 def _get_batch_on_this_cp_rank_in_megatron_cp(batch, cp_size=None, cp_rank=None, seq_length=None):

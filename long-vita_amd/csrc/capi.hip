@@ -62,12 +62,13 @@ static bool fwd_pingpong(int d) {
 }
 // Query rows per forward work item: 256 (8 waves per workgroup); with the lockstep kernel forced,
 // LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
+// Follows lvattn_select_fwd_kernel: descriptors must be (re)built with the block size in force at launch time.
 static int fwd_waves() {
-    static int w = [] {
+    static const bool four = [] {
         const char* e = getenv("LVATTN_FWD_WAVES");
-        return (e && atoi(e) == 4 && fwd_kernel_override() == 2) ? 4 : 8;
+        return e && atoi(e) == 4;
     }();
-    return w;
+    return (four && fwd_kernel_override() == 2) ? 4 : 8;
 }
 extern "C" int lvattn_fwd_block_m(void) { return fwd_waves() * 32; }
 extern "C" const char* lvattn_last_error(void) { return g_err; }
@@ -343,8 +344,11 @@ extern "C" int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk,
                             int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs,
                             int64_t lse_stride, void* stream) {
     if (!out_acc || !lse_acc || !out_blk || !lse_blk) return fail(LV_EINVAL, "null pointer");
-    if (d % 8 || rows < 0 || hq <= 0) return fail(LV_EINVAL, "bad shape");
+    // the in-place lse update needs the d/8 threads of a (row, head) inside one wave: d/8 must divide 64
+    if (d != 64 && d != 128) return fail(LV_EINVAL, "lvattn_merge: head dim %d not supported (64 or 128)", d);
+    if (rows < 0 || hq <= 0 || row0 < 0 || lse_stride < (int64_t)row0 + rows) return fail(LV_EINVAL, "lvattn_merge: bad shape");
     if ((blk_rs | blk_hs) & 7) return fail(LV_EINVAL, "block strides must be multiples of 8");
+    if (((uintptr_t)out_acc | (uintptr_t)out_blk) & 15) return fail(LV_EINVAL, "lvattn_merge: out_acc / out_blk must be 16-byte aligned");
     if (rows == 0) return LV_OK;
     int64_t total = (int64_t)rows * hq * (d / 8);
     int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);

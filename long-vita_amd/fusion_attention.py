@@ -45,6 +45,16 @@ def _is_causal(atten_mask, sparse_mode, pre_tockens, next_tockens):
     raise NotImplementedError(f"sparse_mode={sparse_mode}")
 
 
+def _check_band(causal, sparse_mode, pre_tockens, longest):
+    """In band mode (sparse_mode 4, or 0 / 1 with a mask) the NPU op limits a query to the ``pre_tockens`` keys
+    before it; the kernels here have no band, so a segment longer than the band would silently see more keys than
+    the reference's op lets it.  Modes 2 / 3 ignore pre_tockens (the compressed causal template)."""
+    if causal and sparse_mode in (0, 1, 4) and pre_tockens is not None and longest > pre_tockens:
+        raise NotImplementedError(f"a segment of {longest} tokens exceeds pre_tockens={pre_tockens} in band mode "
+                                  f"(sparse_mode={sparse_mode}): banded causal attention is not built; raise "
+                                  "--pre-tockens to the sequence length or use sparse_mode 2")
+
+
 def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, padding_mask=None, atten_mask=None,
                          scale=1.0, keep_prob=1.0, pre_tockens=2147483647, next_tockens=2147483647, inner_precise=0,
                          prefix=None, actual_seq_qlen=None, actual_seq_kvlen=None, sparse_mode=0, gen_mask_parallel=True,
@@ -63,6 +73,7 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
         if actual_seq_kvlen is not None and list(actual_seq_kvlen) != list(actual_seq_qlen):
             raise NotImplementedError("different q / kv segmentations are not supported")
         cu = ops.cu_seqlens_from_actual_seq_len(actual_seq_qlen)
+        _check_band(causal, sparse_mode, pre_tockens, max((b - a for a, b in zip(cu[:-1], cu[1:])), default=0))
         out, lse = ops.varlen_attention(query, key, value, cu, scale, causal)
         return out, lse, torch.ones_like(lse)
 
@@ -76,6 +87,7 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
         v3 = value.reshape(value.shape[0], b * hkv, d)
         if k3.shape[0] != s:
             raise NotImplementedError("q and kv lengths differ")
+        _check_band(causal, sparse_mode, pre_tockens, s)
         out, lse = ops.varlen_attention(q3, k3, v3, [0, s], scale, causal)
         return out.reshape(s, b, hd), lse, torch.ones_like(lse)
 
@@ -91,6 +103,7 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
             d = hd // head_num
             to_t = lambda x: x.reshape(b * s, x.shape[2] // d, d)
         cu = [i * s for i in range(b + 1)]
+        _check_band(causal, sparse_mode, pre_tockens, s)
         out, lse = ops.varlen_attention(to_t(query), to_t(key), to_t(value), cu, scale, causal)
         if input_layout == "BNSD":
             out = out.reshape(b, s, -1, d).permute(0, 2, 1, 3)

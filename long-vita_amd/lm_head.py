@@ -6,7 +6,8 @@ keeps the selected rows of the hidden states only (``torch.masked_select`` form 
 lcvlm_modellink/core/models/multimodal/gpt_vl_model.py:306-312; labels selected the same way at :346-357),
 and the generation loop builds the mask for the one position it samples from
 (tasks/inference/text_generation/utils.py:357-366, then :378-398 with ``sync_output`` under context
-parallelism).  Here the row selection is a HIP row gather; the projection itself is a library GEMM.
+parallelism).  Here the row selection is a HIP row gather (differentiable: the gradient of the selected rows is
+scattered back, every other position gets zero, as ``masked_select`` does); the projection itself is a library GEMM.
 """
 from __future__ import annotations
 
@@ -33,7 +34,7 @@ def select_hidden_states(hidden_states: torch.Tensor, logit_mask: torch.Tensor) 
     s, b, c = hidden_states.shape
     assert b == 1
     index = torch.nonzero(logit_mask.transpose(0, 1).reshape(-1), as_tuple=False).reshape(-1)
-    return ops.gather_rows(hidden_states.reshape(s * b, c), index).reshape(-1, b, c)
+    return ops.gather_rows(hidden_states.reshape(s * b, c), index, unique_index=True).reshape(-1, b, c)
 
 
 def select_labels(labels: torch.Tensor, logit_mask: torch.Tensor) -> torch.Tensor:

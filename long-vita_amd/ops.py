@@ -98,13 +98,19 @@ class _BlockCache:
 _blocks = _BlockCache()
 
 
+def _block_rows(backward: bool) -> int:
+    """Rows per work item of the kernel that will run: part of every cache key, since the forward value follows the
+    forward kernel selected at run time (lvattn_select_fwd_kernel)."""
+    return LV_BWD_BLOCK_N if backward else _lib.lib().lvattn_fwd_block_m()
+
+
 def blocks_on_device(cu_seqlens: Sequence[int], causal: bool, backward: bool, device) -> torch.Tensor:
-    key = ("seg", tuple(int(x) for x in cu_seqlens), bool(causal), bool(backward), str(device))
+    key = ("seg", tuple(int(x) for x in cu_seqlens), bool(causal), bool(backward), str(device), _block_rows(backward))
     return _blocks.get(key, lambda: torch.from_numpy(build_blocks_host(cu_seqlens, causal, backward)).to(device))
 
 
 def rect_blocks_on_device(q_row0, q_len, k_row0, k_len, causal, shift, backward, device) -> torch.Tensor:
-    key = ("rect", q_row0, q_len, k_row0, k_len, bool(causal), shift, bool(backward), str(device))
+    key = ("rect", q_row0, q_len, k_row0, k_len, bool(causal), shift, bool(backward), str(device), _block_rows(backward))
     return _blocks.get(key, lambda: torch.from_numpy(
         build_rect_blocks_host(q_row0, q_len, k_row0, k_len, causal, shift, backward)).to(device))
 
@@ -115,7 +121,7 @@ def rects_blocks_on_device(rects, backward: bool, device) -> torch.Tensor:
     the rectangle dense).  The rectangles of one launch must not share query rows (forward, dQ) or key rows (dK/dV).
     Heaviest work items first, as for a single rectangle."""
     rects = tuple(tuple(int(x) for x in r) for r in rects)
-    key = ("rects", rects, bool(backward), str(device))
+    key = ("rects", rects, bool(backward), str(device), _block_rows(backward))
 
     def build():
         parts = [build_rect_blocks_host(q0, ql, k0, kl, True, sh, backward) for q0, ql, k0, kl, sh in rects]
@@ -307,25 +313,113 @@ def pixel_shuffle_tokens_launch(vit_output: torch.Tensor, skip: int = 1) -> torc
 
 
 def scatter_rows_(dst: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor, src_index: torch.Tensor | None = None):
-    """dst[dst_index[i]] = src[src_index[i]] over 2-D row views (bf16, contiguous rows)."""
+    """dst[dst_index[i]] = src[src_index[i]] over 2-D row views (bf16, contiguous rows); a raw launch, no autograd:
+    it refuses tensors that are part of a graph (use ``scatter_rows`` for those)."""
+    if torch.is_grad_enabled() and (dst.requires_grad or src.requires_grad):
+        raise LvAttnError("scatter_rows_ is a raw launch without a gradient; call ops.scatter_rows on tensors that need one")
+    return _scatter_rows_launch(dst, dst_index, src, src_index)
+
+
+def _scatter_rows_launch(dst, dst_index, src, src_index=None):
     _require_gpu(dst, src, dst_index)
     if dst.dtype != torch.bfloat16 or src.dtype != torch.bfloat16:
-        raise LvAttnError("scatter_rows_ expects bfloat16")
+        raise LvAttnError("scatter_rows expects bfloat16")
     if not dst.is_contiguous():
-        raise LvAttnError("scatter_rows_ needs a contiguous destination")
+        raise LvAttnError("scatter_rows needs a contiguous destination")
     src = src.contiguous()
     dst_index = dst_index.to(torch.int64).contiguous()
     if src_index is not None:
         src_index = src_index.to(torch.int64).contiguous()
+        if src_index.numel() != dst_index.numel():
+            raise LvAttnError("scatter_rows: source and destination index lists differ in length")
     n = dst_index.numel()
     width = dst.shape[-1]
-    check(_lib.lib().lv_scatter_rows(_ptr(src), _ptr(dst), _ptr(src_index), _ptr(dst_index), n, width,
-                                     src.numel() // width, dst.numel() // width, _stream()), "lv_scatter_rows")
+    if src.shape[-1] != width:
+        raise LvAttnError("scatter_rows: source and destination rows differ in width")
+    if src_index is None and src.numel() // width < n:
+        raise LvAttnError("scatter_rows: fewer source rows than destination indices")
+    if n:
+        check(_lib.lib().lv_scatter_rows(_ptr(src), _ptr(dst), _ptr(src_index), _ptr(dst_index), n, width,
+                                         src.numel() // width, dst.numel() // width, _stream()), "lv_scatter_rows")
     return dst
 
 
-def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
-    """out[i] = src[index[i]] along dim 0 (any dtype whose row size is a multiple of 4 bytes)."""
+class _ScatterRows(torch.autograd.Function):
+    """In-place row scatter with the gradient torch derives for ``dst[index] = src[src_index]``
+    (language_model_embedding.py:123,126,131): the overwritten rows of ``dst`` pass nothing back, the rows of
+    ``src`` that were written somewhere receive the gradient of the row they landed in."""
+
+    @staticmethod
+    def forward(ctx, dst, src, dst_index, src_index):
+        ctx.src_shape = src.shape
+        ctx.has_src_index = src_index is not None
+        ctx.save_for_backward(dst_index, src_index if src_index is not None else dst_index)
+        ctx.mark_dirty(dst)
+        _scatter_rows_launch(dst, dst_index, src, src_index)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        dst_index, src_index = ctx.saved_tensors
+        g = g.contiguous()
+        width = g.shape[-1]
+        g2 = g.view(-1, width)
+        n = dst_index.numel()
+        d_src = d_dst = None
+        if ctx.needs_input_grad[1]:
+            picked = gather_rows_launch(g2, dst_index)                       # gradient of the rows that were written
+            n_src_rows = 1
+            for x in ctx.src_shape[:-1]:
+                n_src_rows *= x
+            if not ctx.has_src_index and n_src_rows == n:
+                d_src = picked.view(ctx.src_shape)
+            else:                                                            # rows never written keep a zero gradient
+                d_src = torch.zeros((n_src_rows, width), dtype=g.dtype, device=g.device)
+                _scatter_rows_launch(d_src, src_index if ctx.has_src_index else torch.arange(n, device=g.device), picked)
+                d_src = d_src.view(ctx.src_shape)
+        if ctx.needs_input_grad[0]:
+            d_dst = g2.clone()
+            zero_row = torch.zeros((1, width), dtype=g.dtype, device=g.device)
+            _scatter_rows_launch(d_dst, dst_index, zero_row, torch.zeros_like(dst_index))
+            d_dst = d_dst.view(g.shape)
+        return d_dst, d_src, None, None
+
+
+def scatter_rows(dst: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor, src_index: torch.Tensor | None = None):
+    """Differentiable ``dst[dst_index[i]] = src[src_index[i]]`` (in place on ``dst``, which must not be a leaf that
+    requires grad, exactly as for torch's own indexed assignment).  ``dst`` [rows, width] contiguous bf16; the
+    destination indices must be distinct, and so must the source indices (both are by construction on this path:
+    lcvlm_modellink/training/utils.py:314-333 builds them from a boolean mask)."""
+    if torch.is_grad_enabled() and (dst.requires_grad or src.requires_grad):
+        return _ScatterRows.apply(dst, src, dst_index, src_index)
+    return _scatter_rows_launch(dst, dst_index, src, src_index)
+
+
+class _KeepGraphAlive(torch.autograd.Function):
+    """``word_embeddings += features.mean() * 0`` (language_model_embedding.py:134, "to avoid backward hanging"):
+    the values stay as they are, ``features`` joins the graph and receives a zero gradient, so that its producer's
+    parameters are used in every step."""
+
+    @staticmethod
+    def forward(ctx, dst, src):
+        ctx.src_shape, ctx.src_dtype = src.shape, src.dtype
+        ctx.mark_dirty(dst)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        d_src = torch.zeros(ctx.src_shape, dtype=ctx.src_dtype, device=g.device) if ctx.needs_input_grad[1] else None
+        return g, d_src
+
+
+def keep_graph_alive_(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    if torch.is_grad_enabled() and (dst.requires_grad or src.requires_grad):
+        return _KeepGraphAlive.apply(dst, src)
+    return dst
+
+
+def gather_rows_launch(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """out[i] = src[index[i]] along dim 0 (any dtype whose row size is a multiple of 4 bytes); no autograd."""
     _require_gpu(src, index)
     src = src.contiguous()
     index = index.to(torch.int64).contiguous()
@@ -333,9 +427,42 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     out = torch.empty((index.numel(),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     if index.numel() == 0 or row_bytes == 0:
         return out
+    if row_bytes % 4:
+        raise LvAttnError("gather_rows: rows must be a multiple of 4 bytes")
     check(_lib.lib().lv_gather_rows(_ptr(src), _ptr(out), _ptr(index), index.numel(), row_bytes, src.shape[0], _stream()),
           "lv_gather_rows")
     return out
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index, unique):
+        ctx.src_shape, ctx.unique = src.shape, unique
+        ctx.save_for_backward(index)
+        return gather_rows_launch(src, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        g = g.contiguous()
+        d_src = torch.zeros(ctx.src_shape, dtype=g.dtype, device=g.device)
+        if index.numel():
+            row_bytes = g[0].numel() * g.element_size()
+            if ctx.unique and row_bytes % 4 == 0:   # a byte move: any dtype goes through the row kernel as 2-byte units
+                _scatter_rows_launch(d_src.view(d_src.shape[0], -1).view(torch.bfloat16), index,
+                                     g.view(g.shape[0], -1).view(torch.bfloat16))
+            else:                                   # repeated rows: their gradients add up
+                d_src.index_add_(0, index.to(torch.int64), g)
+        return d_src, None, None
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor, unique_index: bool = False) -> torch.Tensor:
+    """out[i] = src[index[i]] along dim 0, differentiable in ``src``: the gradient of row j is the sum of the
+    gradients of the output rows that picked it (``unique_index=True`` promises that no row is picked twice, which
+    lets the backward be a plain row scatter)."""
+    if torch.is_grad_enabled() and src.requires_grad:
+        return _GatherRows.apply(src, index, bool(unique_index))
+    return gather_rows_launch(src, index)
 
 
 # ---------------------------------------------------------------------------
@@ -398,15 +525,32 @@ def _bf16_2d(t: torch.Tensor, what: str) -> torch.Tensor:
     return t
 
 
+def _vec(t: torch.Tensor | None, what: str, n: int, like: torch.Tensor, optional: bool = False):
+    """A per-column operand (bias, gamma, LayerScale ...): the kernels read it through a raw pointer as ``n``
+    contiguous bf16 values on ``like``'s device, so anything else must be refused here, not misread there."""
+    if t is None:
+        if optional:
+            return None
+        raise LvAttnError(f"{what} is required")
+    if not t.is_cuda or t.device != like.device:
+        raise LvAttnError(f"{what} must live on {like.device} (got {t.device})")
+    if t.dtype != torch.bfloat16:
+        raise LvAttnError(f"{what} must be bfloat16 (got {t.dtype}); cast the module with .to(torch.bfloat16)")
+    if t.numel() != n:
+        raise LvAttnError(f"{what} has {t.numel()} elements, expected {n}")
+    return t.contiguous()
+
+
 def layernorm_launch(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """LayerNorm over the last dimension of x [..., h] (bf16, fp32 statistics); no autograd."""
     _bf16_2d(x, "layernorm")
     h = x.shape[-1]
+    gamma, beta = _vec(gamma, "layernorm weight", h, x), _vec(beta, "layernorm bias", h, x)
     x2 = x.reshape(-1, h)
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], h), dtype=x.dtype, device=x.device)
-    check(_lib.lib().lv_layernorm(_ptr(x2), _ptr(y), _ptr(gamma.contiguous()), _ptr(beta.contiguous()), x2.shape[0], h,
+    check(_lib.lib().lv_layernorm(_ptr(x2), _ptr(y), _ptr(gamma), _ptr(beta), x2.shape[0], h,
                                   x2.stride(0), y.stride(0), float(eps), _stream()), "lv_layernorm")
     return y.view(x.shape)
 
@@ -414,7 +558,11 @@ def layernorm_launch(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, e
 def layernorm_bwd_launch(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float):
     """Gradients of ``layernorm_launch``: (dx like x, dgamma [h] fp32, dbeta [h] fp32)."""
     _bf16_2d(x, "layernorm_bwd")
+    _require_gpu(dy)
     h = x.shape[-1]
+    gamma = _vec(gamma, "layernorm weight", h, x)
+    if dy.shape != x.shape:
+        raise LvAttnError(f"layernorm_bwd: dy {tuple(dy.shape)} does not match x {tuple(x.shape)}")
     x2, dy2 = x.reshape(-1, h), dy.reshape(-1, h)
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
@@ -425,7 +573,7 @@ def layernorm_bwd_launch(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor,
     dgb = torch.empty((2, h), dtype=torch.float32, device=x.device)
     nbytes = _lib.lib().lv_layernorm_bwd_workspace_bytes(rows, h)
     ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=x.device)
-    check(_lib.lib().lv_layernorm_bwd(_ptr(x2), _ptr(dy2), _ptr(gamma.contiguous()), _ptr(dx), _ptr(dgb), _ptr(ws), nbytes, rows, h,
+    check(_lib.lib().lv_layernorm_bwd(_ptr(x2), _ptr(dy2), _ptr(gamma), _ptr(dx), _ptr(dgb), _ptr(ws), nbytes, rows, h,
                                       x2.stride(0), dy2.stride(0), dx.stride(0), float(eps), _stream()), "lv_layernorm_bwd")
     return dx.view(x.shape), dgb[0], dgb[1]
 
@@ -456,18 +604,23 @@ def bias_gelu_launch(x: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor
     _bf16_2d(x, "bias_gelu")
     x = x.contiguous()
     h = x.shape[-1]
+    bias = _vec(bias, "bias_gelu bias", h, x, optional=True)
     y = torch.empty_like(x)
-    check(_lib.lib().lv_bias_gelu(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(y), x.numel() // h, h,
+    check(_lib.lib().lv_bias_gelu(_ptr(x), _ptr(bias), _ptr(y), x.numel() // h, h,
                                   _stream()), "lv_bias_gelu")
     return y
 
 
 def bias_gelu_bwd_launch(x: torch.Tensor, bias: torch.Tensor | None, dy: torch.Tensor) -> torch.Tensor:
     _bf16_2d(x, "bias_gelu_bwd")
+    _require_gpu(dy)
+    if dy.shape != x.shape:
+        raise LvAttnError(f"bias_gelu_bwd: dy {tuple(dy.shape)} does not match x {tuple(x.shape)}")
     x, dy = x.contiguous(), dy.to(x.dtype).contiguous()
     h = x.shape[-1]
+    bias = _vec(bias, "bias_gelu bias", h, x, optional=True)
     dx = torch.empty_like(x)
-    check(_lib.lib().lv_bias_gelu_bwd(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(dy), _ptr(dx),
+    check(_lib.lib().lv_bias_gelu_bwd(_ptr(x), _ptr(bias), _ptr(dy), _ptr(dx),
                                       x.numel() // h, h, _stream()), "lv_bias_gelu_bwd")
     return dx
 
@@ -497,12 +650,14 @@ def bias_gelu(x: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor
 
 def bias_scale_residual_launch(x: torch.Tensor, bias: torch.Tensor | None, ls: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
     _bf16_2d(x, "bias_scale_residual")
+    _bf16_2d(residual, "bias_scale_residual (residual)")
+    if residual.shape != x.shape or residual.device != x.device:
+        raise LvAttnError("bias_scale_residual: x and residual differ in shape or device")
     x, residual = x.contiguous(), residual.contiguous()
-    if residual.shape != x.shape:
-        raise LvAttnError("bias_scale_residual: x and residual differ in shape")
     h = x.shape[-1]
+    bias, ls = _vec(bias, "bias_scale_residual bias", h, x, optional=True), _vec(ls, "LayerScale vector", h, x)
     out = torch.empty_like(x)
-    check(_lib.lib().lv_bias_scale_residual(_ptr(x), _ptr(bias.contiguous() if bias is not None else None), _ptr(ls.contiguous()),
+    check(_lib.lib().lv_bias_scale_residual(_ptr(x), _ptr(bias), _ptr(ls),
                                             _ptr(residual), _ptr(out), x.numel() // h, h, _stream()), "lv_bias_scale_residual")
     return out
 
@@ -551,13 +706,15 @@ def embed_tokens_launch(proj, conv_bias, class_token, pos_emb) -> torch.Tensor:
     _bf16_2d(proj, "embed_tokens")
     proj = proj.contiguous()
     n, npatch, h = proj.shape
-    ncls = 0 if class_token is None else class_token.reshape(-1, h).shape[0]
-    if pos_emb.shape[0] < npatch + ncls:
-        raise LvAttnError("embed_tokens: position table shorter than the token sequence")
+    ncls = 0 if class_token is None else class_token.numel() // h
+    if pos_emb.dim() != 2 or pos_emb.shape[1] != h or pos_emb.shape[0] < npatch + ncls:
+        raise LvAttnError("embed_tokens: position table must be [>= tokens, h]")
+    conv_bias = _vec(conv_bias, "conv bias", h, proj)
+    class_token = _vec(class_token, "class token", ncls * h, proj, optional=True)
+    pos_emb = _vec(pos_emb, "position embedding", pos_emb.numel(), proj)
     out = torch.empty((npatch + ncls, n, h), dtype=proj.dtype, device=proj.device)
-    check(_lib.lib().lv_embed_tokens(_ptr(proj), _ptr(conv_bias.contiguous()),
-                                     _ptr(class_token.reshape(-1, h).contiguous() if class_token is not None else None),
-                                     _ptr(pos_emb.contiguous()), _ptr(out), n, npatch, ncls, h, _stream()), "lv_embed_tokens")
+    check(_lib.lib().lv_embed_tokens(_ptr(proj), _ptr(conv_bias), _ptr(class_token),
+                                     _ptr(pos_emb), _ptr(out), n, npatch, ncls, h, _stream()), "lv_embed_tokens")
     return out
 
 

@@ -20,51 +20,48 @@ __all__ = ["RotaryEmbedding", "apply_rotary_pos_emb", "apply_rotary_pos_emb_bshd
 
 
 class RotaryEmbedding(torch.nn.Module):
-    """Same constructor and ``forward(max_seq_len, offset)`` as the reference class (:50-122)."""
+    """Angle table of the rotary embedding behind the reference class's interface (:50-122): constructor
+    ``(kv_channels, rotary_percent, rotary_interleaved, seq_len_interpolation_factor, rotary_base)``,
+    ``forward(max_seq_len, offset) -> [s, b | 1, 1, rot]`` fp32 angles, ``get_rotary_seq_len(...)``."""
 
     def __init__(self, kv_channels: int, rotary_percent: float, rotary_interleaved: bool = False,
                  seq_len_interpolation_factor: float = None, rotary_base: int = 10000, device=None) -> None:
         super().__init__()
-        dim = kv_channels
-        if rotary_percent < 1.0:
-            dim = int(dim * rotary_percent)
-        self.rotary_interleaved = rotary_interleaved
-        self.seq_len_interpolation_factor = seq_len_interpolation_factor
+        rot = kv_channels if rotary_percent >= 1.0 else int(kv_channels * rotary_percent)
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else "cpu"
-        self.inv_freq = 1.0 / (rotary_base ** (torch.arange(0, dim, 2, dtype=torch.float32, device=device) / dim))
+        exponent = torch.arange(0, rot, 2, dtype=torch.float32, device=device) / rot
+        self.inv_freq = 1.0 / (rotary_base ** exponent)          # one frequency per rotated column pair
+        self.rotary_interleaved = rotary_interleaved
+        self.seq_len_interpolation_factor = seq_len_interpolation_factor
 
     def forward(self, max_seq_len: int, offset: int = 0) -> torch.Tensor:
-        seq = torch.arange(max_seq_len, device=self.inv_freq.device, dtype=self.inv_freq.dtype) + offset
+        positions = torch.arange(max_seq_len, device=self.inv_freq.device, dtype=self.inv_freq.dtype) + offset
         if self.seq_len_interpolation_factor is not None:
-            seq *= 1 / self.seq_len_interpolation_factor
-        freqs = torch.outer(seq, self.inv_freq)
-        if not self.rotary_interleaved:
-            emb = torch.cat((freqs, freqs), dim=-1)
-        else:
-            emb = torch.stack((freqs.view(-1, 1), freqs.view(-1, 1)), dim=-1).view(freqs.shape[0], -1)
-        emb = emb[:, None, None, :]
+            positions = positions * (1 / self.seq_len_interpolation_factor)   # the product, not a division: same rounding
+        angles = positions[:, None] * self.inv_freq[None, :]                  # [s, rot / 2]
+        # half layout [a0 .. an, a0 .. an] pairs column j with j + rot/2; interleaved layout [a0, a0, a1, a1, ..]
+        table = angles.repeat_interleave(2, dim=-1) if self.rotary_interleaved else angles.repeat(1, 2)
+        table = table[:, None, None, :]
         position_ids = state.get_position_ids()
-        if position_ids is not None:  # [s, b]: positions restart per packed sample
+        if position_ids is not None:      # packed samples: [s, b] positions that restart per sample (:114-117)
             s, b = position_ids.shape
-            emb = emb[position_ids.view(-1)].squeeze(1).reshape(s, b, 1, -1)
-        if state.mpu.get_context_parallel_world_size() > 1:
-            emb = get_pos_emb_on_this_cp_rank(emb, 0)
-        return emb
+            table = table[position_ids.reshape(-1)].reshape(s, b, 1, -1)
+        if state.mpu.get_context_parallel_world_size() > 1:                   # zig-zag slice of this rank (:119-121)
+            table = get_pos_emb_on_this_cp_rank(table, 0)
+        return table
 
     def get_rotary_seq_len(self, inference_params, transformer, transformer_input, transformer_config) -> float:
-        """(:128-159)"""
+        """Length of the table the model asks ``forward`` for (:128-159): the whole sequence, i.e. the local length
+        times every factor by which the sequence dimension is split at this point of the model."""
         if inference_params is not None:
-            rotary_seq_len = inference_params.max_sequence_length
+            local = inference_params.max_sequence_length
         else:
-            if transformer.input_tensor is not None:
-                rotary_seq_len = transformer.input_tensor.size(0)
-            else:
-                rotary_seq_len = transformer_input.size(0)
+            source = transformer.input_tensor if transformer.input_tensor is not None else transformer_input
+            local = source.size(0)
             if transformer_config.sequence_parallel:
-                rotary_seq_len *= transformer_config.tensor_model_parallel_size
-        rotary_seq_len *= transformer_config.context_parallel_size
-        return rotary_seq_len
+                local = local * transformer_config.tensor_model_parallel_size
+        return local * transformer_config.context_parallel_size
 
 
 # cos / sin tables per live `freqs` tensor: id -> (weakref, version, cos, sin)

@@ -39,25 +39,67 @@ def vit_output_to_llm_tokens(vit_output: torch.Tensor, add_class_token: bool = T
 
 
 def scatter_external_features(word_embeddings: torch.Tensor, external_feature_dict: dict) -> torch.Tensor:
-    """In-place scatter into ``word_embeddings`` [b, s, h] (bf16, contiguous)."""
+    """The visual-feature scatter of LanguageModelEmbedding.forward (language_model_embedding.py:103-134), in place
+    on ``word_embeddings`` [b, s, h] (bf16, contiguous; the output of the embedding lookup, not a leaf) and
+    differentiable as the reference's indexed assignments are: ``features`` receives the gradient of the rows it
+    was written to, the overwritten rows of ``word_embeddings`` pass nothing back to the embedding table, and with
+    no index entry at all ``features`` still joins the graph with a zero gradient (:134).  Returns ``word_embeddings``."""
+    assert "features" in external_feature_dict \
+        and (len(external_feature_dict) == 1
+             or len(external_feature_dict) == 2 and "pre_len" in external_feature_dict
+             or len(external_feature_dict) == 2 and "indices" in external_feature_dict
+             or len(external_feature_dict) == 3 and "src_indices" in external_feature_dict
+             and "tgt_indices" in external_feature_dict), "The format of external_feature_dict is not right!"
     features = external_feature_dict["features"]
     b, s, h = word_embeddings.shape
+    flat = word_embeddings.view(b * s, h)
     if "indices" in external_feature_dict:
         ind_b, ind_s = external_feature_dict["indices"].unbind(dim=0)
         dst = (ind_b.reshape(-1) * s + ind_s.reshape(-1))
-        ops.scatter_rows_(word_embeddings.view(b * s, h), dst, features.reshape(-1, features.shape[-1]))
+        ops.scatter_rows(flat, dst, features.reshape(-1, features.shape[-1]))
     elif "pre_len" in external_feature_dict:
         pre = int(external_feature_dict["pre_len"])
         n = features.shape[1]
+        if features.shape[0] != b or pre + n > s:
+            raise ValueError(f"features {tuple(features.shape)} do not fit rows {pre}..{pre + n} of {tuple(word_embeddings.shape)}")
         dst = (torch.arange(b, device=features.device)[:, None] * s + torch.arange(pre, pre + n, device=features.device)[None])
-        ops.scatter_rows_(word_embeddings.view(b * s, h), dst.reshape(-1), features.reshape(-1, h))
+        ops.scatter_rows(flat, dst.reshape(-1), features.reshape(-1, h))
     elif "src_indices" in external_feature_dict and "tgt_indices" in external_feature_dict:
         src_b, src_s = external_feature_dict["src_indices"]
         tgt_b, tgt_s = external_feature_dict["tgt_indices"]
         n_tok = features.shape[1]
-        ops.scatter_rows_(word_embeddings.view(b * s, h), tgt_b * s + tgt_s, features.reshape(-1, features.shape[-1]),
-                          src_b * n_tok + src_s)
+        ops.scatter_rows(flat, tgt_b * s + tgt_s, features.reshape(-1, features.shape[-1]), src_b * n_tok + src_s)
+    else:
+        ops.keep_graph_alive_(flat, features)
     return word_embeddings
+
+
+def language_model_embedding_forward(self, input_ids, position_ids, tokentype_ids=None, external_feature_dict=None):
+    """``LanguageModelEmbedding.forward`` (language_model_embedding.py:91-174) with the scatter above in place of the
+    indexed assignments: same arguments, same attribute reads on ``self`` (``word_embeddings``,
+    ``add_position_embedding`` / ``position_embeddings``, ``tokentype_embeddings``, ``config``,
+    ``embedding_dropout``), result [s, b, h].  Sequence parallelism (a tensor-parallel feature, :157-167) is not on
+    this path and raises."""
+    word_embeddings = self.word_embeddings(input_ids)
+    if external_feature_dict is not None:
+        if not word_embeddings.is_contiguous():
+            word_embeddings = word_embeddings.contiguous()
+        word_embeddings = scatter_external_features(word_embeddings, external_feature_dict)
+    if self.add_position_embedding:
+        embeddings = word_embeddings + self.position_embeddings(position_ids)
+    else:
+        embeddings = word_embeddings
+    embeddings = embeddings.transpose(0, 1).contiguous()
+    if tokentype_ids is not None:
+        assert self.tokentype_embeddings is not None
+        embeddings = embeddings + self.tokentype_embeddings(tokentype_ids).permute(1, 0, 2)
+    else:
+        assert self.tokentype_embeddings is None
+    if self.config.fp32_residual_connection:
+        embeddings = embeddings.float()
+    if self.config.sequence_parallel:
+        raise NotImplementedError("sequence parallelism belongs to tensor parallelism, which this path does not cover")
+    return self.embedding_dropout(embeddings)
 
 
 def vit_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, scale: float | None = None) -> torch.Tensor:

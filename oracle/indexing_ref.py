@@ -180,11 +180,12 @@ def vit_tokens_to_llm_tokens(vit_output: np.ndarray, scale_factor: float = 0.5) 
 
 
 def scatter_features(word_embeddings: np.ndarray, features: np.ndarray, indices=None,
-                     src_indices=None, tgt_indices=None) -> np.ndarray:
-    """language_model_embedding.py:114-131.  ``word_embeddings`` [b,s,h];
-    with ``indices`` [2,n_img,n_tok]: rows (b_idx, s_idx) := features.view(-1,h);
-    with src/tgt: rows tgt := features[src_b, src_s].  Later writes win on
-    duplicates (index_put without accumulate)."""
+                     src_indices=None, tgt_indices=None, pre_len=None) -> np.ndarray:
+    """language_model_embedding.py:114-134.  ``word_embeddings`` [b,s,h];
+    with ``indices`` [2,n_img,n_tok]: rows (b_idx, s_idx) := features.view(-1,h) (:123);
+    with ``pre_len``: rows [:, pre_len:pre_len+n] := features (:126);
+    with src/tgt: rows tgt := features[src_b, src_s] (:131); with none of them the values stay (:134 adds 0).
+    Later writes win on duplicates (index_put without accumulate)."""
     out = word_embeddings.copy()
     if indices is not None:
         b = indices[0].reshape(-1)
@@ -192,10 +193,39 @@ def scatter_features(word_embeddings: np.ndarray, features: np.ndarray, indices=
         f = features.reshape(-1, features.shape[-1])
         for i in range(b.shape[0]):
             out[b[i], s[i]] = f[i]
+    elif pre_len is not None:
+        out[:, pre_len:pre_len + features.shape[1]] = features
     elif src_indices is not None:
         for i in range(src_indices.shape[1]):
             out[tgt_indices[0, i], tgt_indices[1, i]] = features[src_indices[0, i], src_indices[1, i]]
     return out
+
+
+def scatter_features_grad(dout: np.ndarray, features_shape, indices=None, src_indices=None, tgt_indices=None,
+                          pre_len=None):
+    """Gradients torch autograd derives for the assignments above, given ``dout`` [b,s,h] (the gradient of the
+    scattered embeddings): (d_word_embeddings, d_features).  An overwritten row passes nothing back to the word
+    embedding; a feature row receives the gradient of the row it was written to (summed if written twice); with no
+    index at all ``features.mean() * 0`` hands every feature element a zero."""
+    dwe = dout.copy()
+    df = np.zeros(features_shape, dtype=dout.dtype)
+    h = dout.shape[-1]
+    if indices is not None:
+        b = indices[0].reshape(-1)
+        s = indices[1].reshape(-1)
+        f = df.reshape(-1, h)
+        for i in range(b.shape[0]):
+            f[i] += dout[b[i], s[i]]
+            dwe[b[i], s[i]] = 0
+    elif pre_len is not None:
+        n = features_shape[1]
+        df[...] = dout[:, pre_len:pre_len + n]
+        dwe[:, pre_len:pre_len + n] = 0
+    elif src_indices is not None:
+        for i in range(src_indices.shape[1]):
+            df[src_indices[0, i], src_indices[1, i]] += dout[tgt_indices[0, i], tgt_indices[1, i]]
+            dwe[tgt_indices[0, i], tgt_indices[1, i]] = 0
+    return dwe, df
 
 
 def rope_position_gather(table: np.ndarray, position_ids: np.ndarray) -> np.ndarray:

@@ -26,6 +26,10 @@ Fixtures written:
                        apply_rotary_pos_emb_bshd / _thd on bf16 tensors (rotary_pos_embedding.py)
   vit.npz              InternViTTransformerLayer.forward / InternViTModel.forward (intern_vit_model.py)
                        run over the oracle's restatement of the Megatron submodules
+  eager_attention_grad.npz  the same eager wrapper with torch autograd through it (dq / dk / dv), causal and
+                       block-diagonal-causal (packed segments) masks, more than one 256-row query block
+  embedding_scatter.npz  LanguageModelEmbedding.forward (language_model_embedding.py:91-174) in bf16 with autograd:
+                       the visual-feature scatter in its indices / pre_len / src+tgt / no-indices forms
 """
 from __future__ import annotations
 
@@ -168,6 +172,119 @@ def gen_eager_attention():
         out[f"{name}.out_nomask"] = o2.numpy()
     np.savez_compressed(os.path.join(HERE, "eager_attention.npz"), **out)
     print("eager_attention.npz:", len(out), "arrays")
+
+
+def _bf16_bits(t: torch.Tensor) -> np.ndarray:
+    """bf16 tensor -> uint16 bit patterns (half the bytes of the fp32 form, lossless)."""
+    return t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def gen_eager_attention_grad():
+    """Outputs AND gradients of the reference's eager wrapper (dot_product_attention.py:148-288; torch autograd
+    through its baddbmm / softmax / bmm), for plain causal masks and for the block-diagonal-causal mask that packed
+    segments mean.  Inputs are bf16-valued fp32 tensors (stored as bf16 bit patterns); results are fp32."""
+    dpa = importlib.import_module("lcvlm_modellink.core.transformer.dot_product_attention")
+
+    def smsoftmax(scores, mask):   # Megatron FusedScaleMaskSoftmax, unfused fp32 path (not in the reference tree; restated)
+        x = scores.float()
+        if mask is not None:
+            x = x.masked_fill(mask, -10000.0)
+        return torch.softmax(x, dim=-1).to(scores.dtype)
+
+    dpa.get_args = lambda: ns(use_flash_attn=False)
+    dpa.parallel_state = ns(get_global_memory_buffer=lambda: ns(
+        get_tensor=lambda shape, dtype, name: torch.empty(shape, dtype=dtype)))
+    dpa.tensor_parallel = ns(get_cuda_rng_tracker=lambda: ns(fork=contextlib.nullcontext))
+    wrapper = dpa.dot_product_attention_forward_wrapper(lambda *a, **k: None)
+    cases = [
+        # name, sq, np, ng, hn, cu_seqlens (None = one causal segment)
+        ("qwen5to1_causal", 320, 5, 1, 128, None),
+        ("qwen5to1_packed", 300, 5, 1, 128, [0, 37, 38, 170, 261, 300]),   # 1-token segment; 170..261 straddles row 256
+        ("gqa_packed_d64", 200, 4, 2, 64, [0, 64, 65, 200]),
+        ("mha_packed_small", 72, 2, 2, 16, [0, 1, 30, 31, 72]),            # oracle only (the kernels take d = 64 / 128)
+    ]
+    g = torch.Generator().manual_seed(20250101)
+    out = {}
+    for name, sq, np_, ng, hn, cu in cases:
+        q = torch.randn(sq, 1, np_, hn, generator=g).to(torch.bfloat16)
+        k = torch.randn(sq, 1, ng, hn, generator=g).to(torch.bfloat16)
+        v = torch.randn(sq, 1, ng, hn, generator=g).to(torch.bfloat16)
+        do = torch.randn(sq, 1, np_ * hn, generator=g).to(torch.bfloat16)
+        qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+        mask = torch.triu(torch.ones(sq, sq, dtype=torch.bool), 1)
+        if cu is not None:
+            seg = torch.zeros(sq, dtype=torch.long)
+            for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+                seg[a:b] = i
+            mask = mask | (seg[:, None] != seg[None, :])
+        self = ns(num_attention_heads_per_partition=np_, num_query_groups_per_partition=ng,
+                  alibi=None, norm_factor=float(hn) ** 0.5, attn_logit_softcapping=None,
+                  square_alibi_mask=False, scale_mask_softmax=smsoftmax,
+                  config=ns(sequence_parallel=True), attention_dropout=lambda x: x,
+                  hidden_size_per_partition=np_ * hn)
+        o = wrapper(self, qf, kf, vf, mask[None, None], None, None)
+        o.backward(do.float())
+        out[f"{name}.meta"] = np.array([sq, np_, ng, hn], dtype=np.int64)
+        out[f"{name}.cu"] = np.array(cu if cu is not None else [0, sq], dtype=np.int64)
+        out[f"{name}.q"], out[f"{name}.k"], out[f"{name}.v"], out[f"{name}.dout"] = map(_bf16_bits, (q, k, v, do))
+        out[f"{name}.out"] = o.detach().numpy()
+        out[f"{name}.dq"], out[f"{name}.dk"], out[f"{name}.dv"] = qf.grad.numpy(), kf.grad.numpy(), vf.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "eager_attention_grad.npz"), **out)
+    print("eager_attention_grad.npz:", len(out), "arrays")
+
+
+def gen_embedding_scatter():
+    """LanguageModelEmbedding.forward (language_model_embedding.py:91-174) run unbound in bf16 with autograd, for each
+    form of external_feature_dict.  The word-embedding lookup is a stand-in that returns a fresh non-leaf copy of a
+    leaf tensor, so that the leaf's .grad is exactly the gradient that reaches the embedding output."""
+    lme = importlib.import_module("lcvlm_modellink.core.models.common.embeddings.language_model_embedding")
+    lme.mpu = ns(get_context_parallel_world_size=lambda: 1)
+    fwd = lme.LanguageModelEmbedding.forward
+    g = torch.Generator().manual_seed(606)
+    b, s, h, n_img, n_tok = 2, 48, 32, 3, 8
+    out = {"meta": np.array([b, s, h, n_img, n_tok], dtype=np.int64)}
+
+    def run(tag, make_dict):
+        we = torch.randn(b, s, h, generator=g).to(torch.bfloat16).requires_grad_(True)
+        feats = torch.randn(n_img, n_tok, h, generator=g).to(torch.bfloat16).requires_grad_(True)
+        do = torch.randn(s, b, h, generator=g).to(torch.bfloat16)
+        self = ns(word_embeddings=lambda ids: we.clone(), add_position_embedding=False, tokentype_embeddings=None,
+                  config=ns(fp32_residual_connection=False, sequence_parallel=False), embedding_dropout=lambda x: x)
+        d = make_dict(feats)
+        emb = fwd(self, torch.zeros(b, s, dtype=torch.long), None, None, d)
+        assert emb.shape == (s, b, h) and emb.dtype == torch.bfloat16
+        emb.backward(do)
+        out[f"{tag}.we"], out[f"{tag}.features"], out[f"{tag}.dout"] = map(_bf16_bits, (we.detach(), feats.detach(), do))
+        out[f"{tag}.out"] = _bf16_bits(emb.detach())
+        out[f"{tag}.dwe"] = _bf16_bits(we.grad)
+        out[f"{tag}.dfeatures"] = _bf16_bits(feats.grad)
+        for key, val in d.items():
+            if key == "features":
+                continue
+            if key == "pre_len":
+                out[f"{tag}.pre_len"] = np.array(val, dtype=np.int64)
+            elif isinstance(val, (tuple, list)):
+                out[f"{tag}.{key}"] = np.stack([x.numpy() for x in val])
+            else:
+                out[f"{tag}.{key}"] = val.numpy()
+
+    rng = np.random.default_rng(11)
+    starts = [3, 20, 33]
+    ind_s = torch.from_numpy(np.stack([np.arange(st, st + n_tok) for st in starts]).astype(np.int64))
+    ind_b = torch.tensor([0, 1, 1])[:, None].expand(n_img, n_tok).contiguous()
+    run("indices", lambda f: {"features": f, "indices": torch.stack([ind_b, ind_s])})
+    run("pre_len", lambda f: {"features": f[:b], "pre_len": 5})
+    # src/tgt: a CP rank that owns part of image 0, none of image 1, all of image 2 (rows in scrambled order)
+    src_b = torch.tensor([0] * 5 + [2] * n_tok)
+    src_s = torch.tensor([3, 4, 5, 6, 7] + list(range(n_tok)))
+    tgt_b = torch.tensor([0] * 5 + [1] * n_tok)
+    tgt_s = torch.tensor([0, 1, 2, 3, 4] + list(range(30, 30 + n_tok)))
+    perm = torch.from_numpy(rng.permutation(src_b.numel()))
+    run("src_tgt", lambda f: {"features": f, "src_indices": (src_b[perm], src_s[perm]),
+                              "tgt_indices": (tgt_b[perm], tgt_s[perm])})
+    run("none", lambda f: {"features": f})
+    np.savez_compressed(os.path.join(HERE, "embedding_scatter.npz"), **out)
+    print("embedding_scatter.npz:", len(out), "arrays")
 
 
 def gen_indexing():
@@ -519,9 +636,13 @@ def gen_vit():
 
 if __name__ == "__main__":
     install_shim()
-    which = sys.argv[1:] or ["eager", "indexing", "packing", "rope", "vit"]
+    which = sys.argv[1:] or ["eager", "eager_grad", "embedding", "indexing", "packing", "rope", "vit"]
     if "eager" in which:
         gen_eager_attention()
+    if "eager_grad" in which:
+        gen_eager_attention_grad()
+    if "embedding" in which:
+        gen_embedding_scatter()
     if "indexing" in which:
         gen_indexing()
     if "packing" in which:

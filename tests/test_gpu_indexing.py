@@ -181,3 +181,113 @@ def test_logit_mask_selection_matches_masked_select():
     assert lm_head.logit_mask_for_context(toks, 40, 1).nonzero().tolist() == [[0, 39]]
     assert lm_head.logit_mask_for_context(toks, 64 * 3 + 5, 4).nonzero().tolist() == [[0, 4]]
     assert lm_head.logit_mask_for_context(toks, 128, 2).nonzero().tolist() == [[0, 63]]   # index -1, as the reference
+
+
+def _from_bits(bits: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(bits.astype(np.int16)).view(torch.bfloat16)
+
+
+def test_embedding_scatter_with_gradients_matches_reference_fixture(golden_dir):
+    """LanguageModelEmbedding.forward in its four external_feature_dict forms, output AND the gradients that reach
+    the word embeddings and the visual features, against the fixture the reference's own forward + torch autograd
+    produced (language_model_embedding.py:91-174); all data movement, so bit for bit."""
+    from long_vita_amd import vision
+    g = np.load(os.path.join(golden_dir, "embedding_scatter.npz"))
+    b = int(g["meta"][0])
+    for tag in ("indices", "pre_len", "src_tgt", "none"):
+        we = _from_bits(g[f"{tag}.we"]).cuda().requires_grad_(True)
+        feats = _from_bits(g[f"{tag}.features"]).cuda().requires_grad_(True)
+        do = _from_bits(g[f"{tag}.dout"]).cuda()
+        d = {"features": feats}
+        if tag == "indices":
+            d["indices"] = torch.from_numpy(g["indices.indices"]).cuda()
+        elif tag == "pre_len":
+            d = {"features": feats[:b], "pre_len": int(g["pre_len.pre_len"])}
+        elif tag == "src_tgt":
+            d["src_indices"] = tuple(torch.from_numpy(x).cuda() for x in g["src_tgt.src_indices"])
+            d["tgt_indices"] = tuple(torch.from_numpy(x).cuda() for x in g["src_tgt.tgt_indices"])
+        self = types.SimpleNamespace(word_embeddings=lambda ids: we.clone(), add_position_embedding=False,
+                                     tokentype_embeddings=None, embedding_dropout=lambda x: x,
+                                     config=types.SimpleNamespace(fp32_residual_connection=False, sequence_parallel=False))
+        emb = vision.language_model_embedding_forward(self, torch.zeros(b, we.shape[1], dtype=torch.long), None, None, d)
+        emb.backward(do)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(bf16_bits(emb).view(np.uint16), g[f"{tag}.out"], err_msg=tag)
+        np.testing.assert_array_equal(bf16_bits(we.grad).view(np.uint16), g[f"{tag}.dwe"], err_msg=tag)
+        assert feats.grad is not None, tag          # the producer of the features stays in the graph in every form
+        np.testing.assert_array_equal(bf16_bits(feats.grad).view(np.uint16), g[f"{tag}.dfeatures"], err_msg=tag)
+
+
+def test_scatter_refuses_to_sever_a_graph():
+    """The raw launch has no gradient: it must not be usable on tensors that need one."""
+    from long_vita_amd import ops, _lib
+    dst = torch.zeros(8, 16, dtype=torch.bfloat16, device="cuda")
+    src = torch.ones(2, 16, dtype=torch.bfloat16, device="cuda", requires_grad=True)
+    with pytest.raises(_lib.LvAttnError):
+        ops.scatter_rows_(dst, torch.tensor([1, 2], device="cuda"), src)
+    with torch.no_grad():
+        ops.scatter_rows_(dst, torch.tensor([1, 2], device="cuda"), src)
+    assert dst[1].float().sum().item() == 16.0
+
+
+def test_gather_rows_and_masked_logits_are_differentiable():
+    """Row selection must hand gradients back to the hidden states (zero for unselected positions, summed for a
+    row picked twice), as torch.masked_select / index_select do."""
+    from long_vita_amd import lm_head, ops, cp_partition as P
+    g = torch.Generator().manual_seed(9)
+    s, c, vocab = 300, 64, 128
+    hidden = torch.randn(s, 1, c, generator=g).to(torch.bfloat16)
+    w = torch.randn(vocab, c, generator=g).to(torch.bfloat16)
+    mask = torch.rand(1, s, generator=g) < 0.1
+    dlog = torch.randn(int(mask.sum()), 1, vocab, generator=g).to(torch.bfloat16)
+    hc, wc = hidden.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    lm_head.masked_logits(hc, wc, mask.cuda()).backward(dlog.cuda())
+    hr, wr = hidden.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    sel = torch.masked_select(hr, mask.cuda().transpose(0, 1).unsqueeze(2)).reshape(-1, 1, c)
+    torch.nn.functional.linear(sel, wr).backward(dlog.cuda())
+    assert hc.grad is not None and torch.equal(hc.grad, hr.grad) and torch.equal(wc.grad, wr.grad)
+    # repeated rows: gradients add up
+    x = torch.randn(10, 8, generator=g).cuda().requires_grad_(True)
+    idx = torch.tensor([3, 3, 0, 9, 3], device="cuda")
+    ops.gather_rows(x, idx).backward(torch.ones(5, 8, device="cuda"))
+    want = torch.zeros(10, 8); want[3] = 3; want[0] = 1; want[9] = 1
+    assert torch.equal(x.grad.cpu(), want)
+    # the zig-zag slice of an activation
+    act = torch.randn(64, 2, 32, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+    P.zigzag_slice(act, 4, 1, 0).backward(torch.ones(16, 2, 32, dtype=torch.bfloat16, device="cuda"))
+    want = torch.zeros(64, 1, 1); want[8:16] = 1; want[48:56] = 1
+    assert torch.equal(act.grad.float().cpu(), want.expand(64, 2, 32))
+
+
+def test_operands_of_the_elementwise_kernels_are_validated():
+    """The per-column operands travel as raw pointers: a wrong dtype, device or length must raise, not be misread."""
+    from long_vita_amd import ops, _lib
+    x = torch.randn(4, 128, device="cuda").to(torch.bfloat16)
+    good = torch.ones(128, dtype=torch.bfloat16, device="cuda")
+    for bad in (torch.ones(128, device="cuda"), torch.ones(64, dtype=torch.bfloat16, device="cuda"),
+                torch.ones(128, dtype=torch.bfloat16)):
+        with pytest.raises(_lib.LvAttnError):
+            ops.layernorm_launch(x, bad, good, 1e-5)
+        with pytest.raises(_lib.LvAttnError):
+            ops.layernorm_launch(x, good, bad, 1e-5)
+        with pytest.raises(_lib.LvAttnError):
+            ops.bias_gelu_launch(x, bad)
+        with pytest.raises(_lib.LvAttnError):
+            ops.bias_scale_residual_launch(x, good, bad, x)
+        with pytest.raises(_lib.LvAttnError):
+            ops.layernorm_bwd_launch(x, x, bad, 1e-5)
+    with pytest.raises(_lib.LvAttnError):
+        ops.bias_scale_residual_launch(x, good, good, x[:2])
+    ops.layernorm_launch(x, good, good, 1e-5)          # the well-formed call still goes through
+
+
+def test_band_mode_longer_than_pre_tockens_raises():
+    from long_vita_amd.fusion_attention import npu_fusion_attention
+    q = torch.zeros(512, 2, 128, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(NotImplementedError):
+        npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=4,
+                             actual_seq_qlen=[512], actual_seq_kvlen=[512])
+    npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=4,
+                         actual_seq_qlen=[256, 512], actual_seq_kvlen=[256, 512])
+    npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=2,
+                         actual_seq_qlen=[512], actual_seq_kvlen=[512])

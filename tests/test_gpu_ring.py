@@ -105,6 +105,77 @@ def test_ring_two_processes_one_gpu_torch_distributed(tmp_path):
         assert rel(got, ref) <= REL_TOL, name
 
 
+def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len):
+    """One CP rank of the entry-point test: ambient state as Megatron / MindSpeed would hold it, the batch cut by
+    get_batch_on_this_cp_rank, attention through flash_attention_forward, results reassembled by sync_output."""
+    import os
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from long_vita_amd import cp_partition, state
+    from long_vita_amd.core_attention import flash_attention_forward
+    packed = actual_seq_len is not None
+    state.mpu.initialize(dist.group.WORLD, world, rank)
+    state.set_args(state.make_args(context_parallel_size=world, seq_length=S, reset_attention_mask=packed,
+                                   reset_position_ids=packed))
+    state.set_actual_seq_len(actual_seq_len)
+    g = torch.Generator().manual_seed(23)
+    q = torch.randn(S, 1, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, 1, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, 1, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, 1, Hq * D, generator=g).to(torch.bfloat16)
+    # the batch is [b, s, ...] with the sequence on dim 1 (lcvlm_modellink/training/utils.py:351-362)
+    batch = {"q": q.transpose(0, 1).cuda(), "k": k.transpose(0, 1).cuda(), "v": v.transpose(0, 1).cuda(),
+             "do": do.transpose(0, 1).cuda(), "position_ids": torch.arange(S)[None].cuda()}
+    batch = cp_partition.get_batch_on_this_cp_rank(batch)
+    ql, kl, vl = (batch[x].transpose(0, 1).contiguous().requires_grad_(True) for x in "qkv")
+    assert ql.shape == (S // world, 1, Hq, D)
+    me = types.SimpleNamespace(hidden_size_per_attention_head=D, scale_mask_softmax=types.SimpleNamespace(scale=None),
+                               softmax_scale=None, attention_dropout=types.SimpleNamespace(p=0.0), alibi=None,
+                               pse=None, pse_type=None)
+    out = flash_attention_forward(me, ql, kl, vl, None, None, None)
+    assert out.shape == (S // world, 1, Hq * D)
+    out.backward(batch["do"].transpose(0, 1))
+    torch.cuda.synchronize()
+    # sync_output gathers [b, s_local, ...] over the CP group and undoes the zig-zag (tasks/.../utils.py:557-581)
+    whole = {name: cp_partition.sync_output(t.detach().transpose(0, 1).contiguous().cpu())[0]
+             for name, t in (("out", out), ("dq", ql.grad.flatten(2)), ("dk", kl.grad.flatten(2)), ("dv", vl.grad.flatten(2)))}
+    if rank == 0:
+        cu = [0] + list(actual_seq_len) if packed else [0, S]
+        scale = A.default_scale(D)
+        ref_o, _ = A.varlen_attention(q[:, 0], k[:, 0], v[:, 0], cu, scale)
+        rdq, rdk, rdv = A.varlen_attention_grad(q[:, 0], k[:, 0], v[:, 0], do.reshape(S, Hq, D), cu, scale)
+        for name, ref in (("out", ref_o), ("dq", rdq), ("dk", rdk), ("dv", rdv)):
+            err = rel(whole[name].reshape(ref.shape), ref)
+            assert err <= REL_TOL, (name, err)
+    # the hybrid ring x Ulysses algorithm uses another subgroup and partition: it must refuse, not run as one ring
+    state.set_args(state.make_args(context_parallel_size=world, seq_length=S, context_parallel_algo="hybrid_cp_algo"))
+    try:
+        flash_attention_forward(me, ql.detach(), kl.detach(), vl.detach(), None, None, None)
+        raise AssertionError("hybrid_cp_algo ran")
+    except NotImplementedError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("actual_seq_len", [None, [300, 301, 1500, 2048]], ids=["causal", "packed"])
+def test_cp_branches_through_flash_attention_forward_two_processes(actual_seq_len):
+    """The context-parallel branches of the patched entry point (dot_product_attention.py:374-379 generic causal,
+    :339-343 reset_attention_mask + actual_seq_len) end to end in two processes: state.mpu -> cp_para ->
+    ringattn_context_parallel -> HIP ring, forward and backward, inputs cut by get_batch_on_this_cp_rank and results
+    reassembled by sync_output's all_gather, against the oracle on the whole sequence."""
+    import os
+    import torch.multiprocessing as mp
+    port = 35500 + (os.getpid() % 2000) + (0 if actual_seq_len is None else 1)
+    mp.spawn(_entry_worker, args=(2, port, 2048, 10, 2, 128, actual_seq_len), nprocs=2, join=True)
+
+
 class _FeedComm:
     """Stands in for the ring's transport for ONE rank: each exchange delivers, on a side stream, the K / V block the
     rank would receive at that step (the zig-zag shard of rank r - step - 1), taken from the whole K / V."""

@@ -244,7 +244,12 @@ def test_image_to_llm_embedding_end_to_end():
     assert new_len == cur_len + 258
     emb = _bf(1, seq, 5120, seed=62).cuda()
     before = emb.clone()
-    out = vision.scatter_external_features(emb, {"features": feats.detach(), "indices": image_indices.cuda()})
+    assert feats.requires_grad                                              # the projector trains in every stage
+    out = vision.scatter_external_features(emb, {"features": feats, "indices": image_indices.cuda()})
+    assert out.requires_grad                                                # the scatter keeps the projector in the graph
+    (out.float() * 0.5).sum().backward()
+    w2 = m.vision_projection.encoder.linear_fc2.weight
+    assert w2.grad is not None and float(w2.grad.float().abs().max()) > 0
     pos = image_indices[1, 0]
     assert torch.equal(out[0, pos], feats.detach()[0])                      # the 256 context rows, bit for bit
     keep = torch.ones(seq, dtype=torch.bool)
@@ -287,3 +292,49 @@ def test_frozen_tower_builds_no_graph():
     m = iv.InternViTModel(cfg).to(torch.bfloat16).cuda()
     out = m(_bf(2, 3, 28, 28, seed=81).cuda())
     assert not out.requires_grad
+
+
+def _vision_cp_worker(rank, world, port):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from long_vita_amd import intern_vit as iv, vision_model as vmod
+    from long_vita_amd.vision_parallel import encode_images_context_parallel, images_needed_by_rank
+    cfg = iv.InternViTConfig(hidden_size=128, ffn_hidden_size=256, num_attention_heads=2, num_layers=2, img_h=56, img_w=56)
+    torch.manual_seed(5)                                     # the same weights on both ranks
+    m = vmod.MegatronVisionModel(hidden_size=64, vit_config=cfg, vision_projector_freeze=True).to(torch.bfloat16).cuda()
+    T = m.image_token_length
+    assert T == 4
+    S, n_img = 256, 7
+    images = _bf(n_img, 3, 56, 56, seed=91).cuda()
+    starts = torch.tensor([1, 11, 21, 62, 100, 61 + 64, 200])        # image 3 straddles the chunk edge at 64
+    ind_s = starts[:, None] + torch.arange(T)[None]
+    ext = torch.stack([torch.zeros_like(ind_s), ind_s]).cuda()
+    calls = []
+
+    def encode(x):
+        calls.append(x.shape[0])
+        return m(images=x)
+    got = encode_images_context_parallel(images, ext, S, world, rank, encode, dist.group.WORLD)
+    need = images_needed_by_rank(ext, S, world, rank)
+    want = m(images=images[need])                            # what the reference's per-rank encode holds
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (need.numel(), T, 64)
+    assert calls == [4 if rank == 0 else 3], calls           # 7 images dealt 4 + 3, whatever each rank needs
+    err = (got.float() - want.float()).abs().max().item()
+    assert err <= 2e-2 * want.float().abs().max().item(), err    # batch composition differs, so GEMM tiling may too
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_image_encode_dealt_over_cp_ranks_two_processes_real_model():
+    """vision_parallel on the GPU: two processes (gloo group; both ranks share the box's one GPU), the real
+    MegatronVisionModel as the encoder, features routed point to point to the ranks that own tokens of each image."""
+    import os
+    import torch.multiprocessing as mp
+    mp.spawn(_vision_cp_worker, args=(2, 37500 + (os.getpid() % 2000)), nprocs=2, join=True)

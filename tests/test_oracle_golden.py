@@ -139,3 +139,53 @@ def test_pack_samples_matches_reference_add_ret_process_ret(golden_dir):
         np.testing.assert_array_equal(actual, g[f"{name}.actual_seq_len"], err_msg=name)
         np.testing.assert_array_equal(pids, g[f"{name}.position_ids"], err_msg=name)
         np.testing.assert_array_equal(img, g[f"{name}.image_indices"], err_msg=name)
+
+
+def _bits_to_f32(bits: np.ndarray) -> np.ndarray:
+    """uint16 bf16 bit patterns -> float32 values."""
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+GRAD_CASES = ["qwen5to1_causal", "qwen5to1_packed", "gqa_packed_d64", "mha_packed_small"]
+
+
+def test_fp64_attention_and_grad_match_autograd_of_reference_wrapper(golden_dir):
+    """Outputs and dq / dk / dv of the float64 restatement against torch autograd through the REFERENCE's eager
+    wrapper (fixture), for causal and packed (block-diagonal-causal) masks, 5:1 head ratio, d = 128 past one
+    256-row block.  The wrapper's softmax runs in fp32, hence 1e-4 of the tensor's scale rather than 1e-12."""
+    g = _load(golden_dir, "eager_attention_grad.npz")
+    for name in GRAD_CASES:
+        sq, np_, ng, hn = (int(x) for x in g[f"{name}.meta"])
+        cu = [int(x) for x in g[f"{name}.cu"]]
+        q, k, v = (_bits_to_f32(g[f"{name}.{x}"])[:, 0] for x in "qkv")
+        do = _bits_to_f32(g[f"{name}.dout"])[:, 0].reshape(sq, np_, hn)
+        o, _ = A.varlen_attention(q, k, v, cu, A.default_scale(hn), True)
+        dq, dk, dv = A.varlen_attention_grad(q, k, v, do, cu, A.default_scale(hn), True)
+        for got, key in ((o.reshape(sq, 1, -1), "out"), (dq[:, None], "dq"), (dk[:, None], "dk"), (dv[:, None], "dv")):
+            ref = g[f"{name}.{key}"].astype(np.float64)
+            assert got.shape == ref.shape, (name, key)
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (name, key, np.abs(got - ref).max())
+
+
+def test_scatter_oracle_matches_reference_embedding_forward(golden_dir):
+    """oracle scatter (+ its gradient) against LanguageModelEmbedding.forward run in bf16 with autograd (fixture):
+    pure data movement, so bit-exact."""
+    g = _load(golden_dir, "embedding_scatter.npz")
+    for tag in ("indices", "pre_len", "src_tgt", "none"):
+        we, feats, do = (_bits_to_f32(g[f"{tag}.{x}"]) for x in ("we", "features", "dout"))
+        kw = {}
+        if tag == "indices":
+            kw["indices"] = g["indices.indices"]
+        elif tag == "pre_len":
+            kw["pre_len"] = int(g["pre_len.pre_len"])
+        elif tag == "src_tgt":
+            kw["src_indices"], kw["tgt_indices"] = g["src_tgt.src_indices"], g["src_tgt.tgt_indices"]
+        ref_df = _bits_to_f32(g[f"{tag}.dfeatures"])
+        if tag == "pre_len":      # the fixture handed the first b images' features over; the rest got no gradient
+            assert not ref_df[we.shape[0]:].any()
+            feats, ref_df = feats[:we.shape[0]], ref_df[:we.shape[0]]
+        out = I.scatter_features(we, feats, **kw).transpose(1, 0, 2)          # [b,s,h] -> [s,b,h] (:142)
+        np.testing.assert_array_equal(out, _bits_to_f32(g[f"{tag}.out"]), err_msg=tag)
+        dwe, df = I.scatter_features_grad(do.transpose(1, 0, 2), feats.shape, **kw)
+        np.testing.assert_array_equal(dwe, _bits_to_f32(g[f"{tag}.dwe"]), err_msg=tag)
+        np.testing.assert_array_equal(df, ref_df, err_msg=tag)
