@@ -116,6 +116,24 @@ int lvattn_decode(const void* q, const void* k, const void* v, void* out, float*
                   int64_t o_batch_stride, int64_t o_head_stride,
                   float softmax_scale, int n_split, void* stream);
 
+/* lvattn_decode without any allocation, by the caller or the library: the key ranges' partial results go to a fixed
+ * buffer inside the library image (lvattn_decode_noalloc_max_bytes() = 8 MiB per GPU, held from the first call on
+ * that GPU until the process ends) instead of a caller's workspace.  No counterpart in the reference; it is for
+ * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same arguments and results as lvattn_decode minus the workspace.  Returns LV_ESIZE when
+ * batch * hkv * n_split * (hq / hkv) * (d + 1) * 4 bytes exceed the buffer (pass a smaller n_split or use
+ * lvattn_decode); the 40 / 8-head, d = 128 shape fits up to batch 6 at the default split.  All calls on one GPU
+ * share the buffer: calls that overlap on one GPU (two streams, two threads) race and must be serialised by the
+ * caller. */
+int64_t lvattn_decode_noalloc_max_bytes(void);
+int lvattn_decode_noalloc(const void* q, const void* k, const void* v, void* out, float* lse,
+                          int batch, int k_len, int hq, int hkv, int d,
+                          int64_t q_batch_stride, int64_t q_head_stride,
+                          int64_t k_batch_stride, int64_t k_row_stride, int64_t k_head_stride,
+                          int64_t v_batch_stride, int64_t v_row_stride, int64_t v_head_stride,
+                          int64_t o_batch_stride, int64_t o_head_stride,
+                          float softmax_scale, int n_split, void* stream);
+
 /* ---- attention backward -----------------------------------------------------
  * Replaces the autograd of the calls above (npu_fusion_attention_grad, reached
  * through torch autograd from dot_product_attention.py:352-365 / :314-325) and the

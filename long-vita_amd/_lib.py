@@ -45,6 +45,9 @@ _SIGNATURES = {
     "lvattn_decode_workspace_bytes": (_i64, [_int, _int, _int, _int]),
     "lvattn_decode": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int,
                              _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _vp]),
+    "lvattn_decode_noalloc_max_bytes": (_i64, []),
+    "lvattn_decode_noalloc": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
+                                     _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _vp]),
     "lv_layernorm": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _f, _vp]),
     "lv_bias_gelu": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "lv_bias_gelu_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -213,19 +214,44 @@ extern "C" int64_t lvattn_decode_workspace_bytes(int batch, int hq, int hkv, int
     return (int64_t)batch * hkv * LV_DECODE_MAX_SPLITS * group * (d + 1) * (int64_t)sizeof(float);
 }
 
-extern "C" int lvattn_decode(const void* q, const void* k, const void* v, void* out, float* lse, void* workspace,
-                             int64_t workspace_bytes, int batch, int k_len, int hq, int hkv, int d,
-                             int64_t q_bs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
-                             int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_hs,
-                             float scale, int n_split, void* stream) {
+// The same kernels with the key ranges' partial results in a buffer that is part of the library image instead of a
+// caller's workspace: nothing is allocated, by the caller or here.  Every GPU the library runs on holds its own copy
+// of the array at its own address; the array's name is only a host-side handle, the device address comes from
+// hipGetSymbolAddress, once per device, with that device current.
+static __device__ __align__(256) unsigned char scratch[LV_DECODE_SCRATCH_BYTES];
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[LV_MAX_DEVICES] = {};
+
+static int scratch_of_current_device(void** ptr) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(LV_ELAUNCH, "lvattn_decode_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= LV_MAX_DEVICES) return fail(LV_EINVAL, "lvattn_decode_noalloc: device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(LV_ELAUNCH, "lvattn_decode_noalloc: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *ptr = g_scratch_ptr[dev];
+    return LV_OK;
+}
+
+static int decode_impl(const char* who, const void* q, const void* k, const void* v, void* out, float* lse, void* workspace,
+                       int64_t workspace_bytes, int batch, int k_len, int hq, int hkv, int d,
+                       int64_t q_bs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                       int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_hs,
+                       float scale, int n_split, void* stream, bool library_scratch) {
     if (int e = check_common(q, k, v, hq, hkv, d, q_bs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
-    if (!out || !workspace) return fail(LV_EINVAL, "lvattn_decode: null out/workspace pointer");
-    if (batch <= 0 || k_len <= 0) return fail(LV_EINVAL, "lvattn_decode: batch=%d k_len=%d", batch, k_len);
-    if (hq / hkv > 32) return fail(LV_EINVAL, "lvattn_decode: %d query heads per KV head (at most 32)", hq / hkv);
-    if ((k_bs | v_bs) & 7) return fail(LV_EINVAL, "lvattn_decode: batch strides must be multiples of 8 elements");
-    if ((uintptr_t)workspace & 15) return fail(LV_EINVAL, "lvattn_decode: workspace must be 16-byte aligned");
+    if (!out || (!workspace && !library_scratch)) return fail(LV_EINVAL, "%s: null out/workspace pointer", who);
+    if (batch <= 0 || k_len <= 0) return fail(LV_EINVAL, "%s: batch=%d k_len=%d", who, batch, k_len);
+    if (hq / hkv > 32) return fail(LV_EINVAL, "%s: %d query heads per KV head (at most 32)", who, hq / hkv);
+    if ((k_bs | v_bs) & 7) return fail(LV_EINVAL, "%s: batch strides must be multiples of 8 elements", who);
+    if ((uintptr_t)workspace & 15) return fail(LV_EINVAL, "%s: workspace must be 16-byte aligned", who);
     // the tile loads address a split's rows with 32-bit byte offsets
-    if ((int64_t)LV_DECODE_TILE * (k_rs > v_rs ? k_rs : v_rs) * 2 > 0x7fffffffLL) return fail(LV_EINVAL, "lvattn_decode: row stride too large");
+    if ((int64_t)LV_DECODE_TILE * (k_rs > v_rs ? k_rs : v_rs) * 2 > 0x7fffffffLL) return fail(LV_EINVAL, "%s: row stride too large", who);
     const int max_split = (k_len + LV_DECODE_TILE - 1) / LV_DECODE_TILE;
     if (n_split <= 0) n_split = (512 + batch * hkv - 1) / (batch * hkv);   // two workgroups per CU
     if (n_split > max_split) n_split = max_split;
@@ -235,8 +261,12 @@ extern "C" int lvattn_decode(const void* q, const void* k, const void* v, void* 
     n_split = (k_len + chunk - 1) / chunk;
     const int group = hq / hkv;
     const int64_t need = (int64_t)batch * hkv * n_split * group * (d + 1) * (int64_t)sizeof(float);
-    if (workspace_bytes < need) return fail(LV_EINVAL, "lvattn_decode: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
-    if ((int64_t)batch * hkv * n_split > 0x7fffffffLL) return fail(LV_EINVAL, "lvattn_decode: grid too large");
+    if (workspace_bytes < need)
+        return fail(LV_ESIZE, "%s: %lld bytes of partial results needed (batch %d x %d KV heads x %d key ranges x %d heads x (%d + 1) floats), "
+                    "room for %lld", who, (long long)need, batch, hkv, n_split, group, d, (long long)workspace_bytes);
+    if ((int64_t)batch * hkv * n_split > 0x7fffffffLL) return fail(LV_EINVAL, "%s: grid too large", who);
+    if (library_scratch)   // the first HIP call: every argument has been checked by now
+        if (int e = scratch_of_current_device(&workspace)) return e;
     DecodeParams p;
     p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.o = (__bf16*)out; p.lse = lse;
     p.part_o = (float*)workspace;
@@ -245,8 +275,30 @@ extern "C" int lvattn_decode(const void* q, const void* k, const void* v, void* 
     p.q_bs = q_bs; p.q_hs = q_hs; p.k_bs = k_bs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_bs = v_bs; p.v_rs = v_rs; p.v_hs = v_hs;
     p.o_bs = o_bs; p.o_hs = o_hs;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (lv_launch_decode(p, d, (hipStream_t)stream)) return fail(LV_ELAUNCH, "lvattn_decode: launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (lv_launch_decode(p, d, (hipStream_t)stream)) return fail(LV_ELAUNCH, "%s: launch failed: %s", who, hipGetErrorString(hipGetLastError()));
     return LV_OK;
+}
+
+extern "C" int lvattn_decode(const void* q, const void* k, const void* v, void* out, float* lse, void* workspace,
+                             int64_t workspace_bytes, int batch, int k_len, int hq, int hkv, int d,
+                             int64_t q_bs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                             int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_hs,
+                             float scale, int n_split, void* stream) {
+    return decode_impl("lvattn_decode", q, k, v, out, lse, workspace, workspace_bytes, batch, k_len, hq, hkv, d, q_bs, q_hs,
+                       k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_hs, scale, n_split, stream, false);
+}
+
+extern "C" int64_t lvattn_decode_noalloc_max_bytes(void) { return LV_DECODE_SCRATCH_BYTES; }
+
+extern "C" int lvattn_decode_noalloc(const void* q, const void* k, const void* v, void* out, float* lse,
+                                     int batch, int k_len, int hq, int hkv, int d,
+                                     int64_t q_bs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                                     int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_hs,
+                                     float scale, int n_split, void* stream) {
+    // every partial result the merge kernel reads is written by the first kernel of the same call (each key range is
+    // non-empty by construction), so nothing of the previous call's contents has to be cleared
+    return decode_impl("lvattn_decode_noalloc", q, k, v, out, lse, nullptr, LV_DECODE_SCRATCH_BYTES, batch, k_len, hq, hkv, d,
+                       q_bs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_hs, scale, n_split, stream, true);
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,8 @@ int lv_launch_fwd_pp16(const FwdParams& p, int causal, hipStream_t stream);     
 // Incremental attention over a KV cache: q [batch, hq, d], k/v [batch, k_len, hkv, d], out [batch, hq, d].
 #define LV_DECODE_MAX_SPLITS 256
 #define LV_DECODE_TILE 128
+#define LV_DECODE_SCRATCH_BYTES (8 << 20)   // partial results of lvattn_decode_noalloc, held by every GPU the library runs on
+#define LV_MAX_DEVICES 64
 struct DecodeParams {
     const __bf16* q;
     const __bf16* k;

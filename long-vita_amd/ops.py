@@ -164,9 +164,12 @@ def attn_fwd_launch(q, k, v, desc: torch.Tensor, scale: float, causal: bool, out
     return out, lse
 
 
-def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, n_split: int = 0, return_lse: bool = False):
+def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, n_split: int = 0, return_lse: bool = False,
+                     out: torch.Tensor | None = None, lse: torch.Tensor | None = None, library_scratch: bool = False):
     """One new token per sequence against a KV cache: q [b, hq, d], k / v [b, k_len, hkv, d] bf16 (any batch / row /
-    head strides, last dimension contiguous) -> out [b, hq, d] (and lse [b, hq] fp32)."""
+    head strides, last dimension contiguous) -> out [b, hq, d] (and lse [b, hq] fp32).  With ``library_scratch`` the
+    partial results live in the library's own fixed buffer (lvattn_decode_noalloc): given ``out`` (and ``lse``) the
+    call then allocates nothing, at the price of a size limit and of calls on one GPU having to be serialised."""
     _require_gpu(q, k, v)
     if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
         raise LvAttnError("q, k, v must be bfloat16")
@@ -175,8 +178,20 @@ def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
     q, k, v = _last_contig(q), _last_contig(k), _last_contig(v)
     b, hq, d = q.shape
     _, k_len, hkv, _ = k.shape
-    out = torch.empty((b, hq, d), dtype=torch.bfloat16, device=q.device)
-    lse = torch.empty((b, hq), dtype=torch.float32, device=q.device) if return_lse else None
+    if out is None:
+        out = torch.empty((b, hq, d), dtype=torch.bfloat16, device=q.device)
+    elif out.shape != (b, hq, d) or out.dtype != torch.bfloat16 or out.device != q.device or out.stride(2) != 1:
+        raise LvAttnError("decode_attention: out must be bf16 [b, hq, d] on q's device with a contiguous last dimension")
+    if lse is None:
+        lse = torch.empty((b, hq), dtype=torch.float32, device=q.device) if return_lse else None
+    elif lse.shape != (b, hq) or lse.dtype != torch.float32 or lse.device != q.device or not lse.is_contiguous():
+        raise LvAttnError("decode_attention: lse must be contiguous fp32 [b, hq] on q's device")
+    if library_scratch:
+        check(_lib.lib().lvattn_decode_noalloc(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), b, k_len, hq, hkv, d,
+                                               q.stride(0), q.stride(1), k.stride(0), k.stride(1), k.stride(2),
+                                               v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1),
+                                               float(scale), int(n_split), _stream()), "lvattn_decode_noalloc")
+        return (out, lse) if return_lse else out
     nbytes = _lib.lib().lvattn_decode_workspace_bytes(b, hq, hkv, d)
     ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=q.device)
     check(_lib.lib().lvattn_decode(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(ws), nbytes, b, k_len, hq, hkv, d,

@@ -126,7 +126,11 @@ def test_argument_validation_rejects_before_any_launch():
     rc = L.lvattn_decode(p, p, p, p, None, p, ws, 1, 0, 40, 8, 128, 5120, 128, 1024, 1024, 128, 1024, 1024, 128, 5120, 128, f, 0, None)
     assert rc != 0 and "k_len" in err()
     rc = L.lvattn_decode(p, p, p, p, None, p, 16, 1, 100000, 40, 8, 128, 5120, 128, 1024, 1024, 128, 1024, 1024, 128, 5120, 128, f, 0, None)
-    assert rc != 0 and "workspace" in err()
+    assert rc == -3 and "bytes of partial results needed" in err()        # LV_ESIZE
+    # the allocation-free form: same checks, and its fixed buffer bounds the shape (nothing is launched for either)
+    assert L.lvattn_decode_noalloc_max_bytes() == 8 << 20
+    rc = L.lvattn_decode_noalloc(p, p, p, p, None, 1, 0, 40, 8, 128, 5120, 128, 1024, 1024, 128, 1024, 1024, 128, 5120, 128, f, 0, None)
+    assert rc != 0 and "k_len" in err()
     # LayerNorm backward: rows wider than it supports
     rc = L.lv_layernorm_bwd(p, p, p, p, p, p, 1 << 20, 4, 8192, 8192, 8192, 8192, C.c_float(1e-5), None)
     assert rc != 0 and "4096" in err()
