@@ -129,9 +129,32 @@ def cpu_baseline(seq, rows=1024, heads=(0, 1)):
         reps += 1
     dt = total / reps
     full = dt * (seq / rows) * (HQ / len(heads))
-    return {"value": seq / full, "unit": "tokens/s", "cores": threads, "kind": "port",
+    return {"value": seq / full, "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{rows} query rows x {seq} keys x {len(heads)} of {HQ} heads, fp32 eager baddbmm/softmax/bmm, "
                       f"{reps} passes, {total:.1f}s measured, extrapolated linearly in rows x heads"}
+
+
+def cpu_baseline_cfg1():
+    """BASELINE configs[0] in full on the host cores: the eager path over 8,192 packed tokens in the five segments
+    [258, 1290, 3000, 5120, 8192] (cumulative ends), all 40 query heads, one head at a time (the [40, 8192, 8192]
+    score tensor would not fit at once)."""
+    from oracle import attention_ref as A
+    T, ends = 8192, [258, 1290, 3000, 5120, 8192]
+    g = torch.Generator().manual_seed(0)
+    seg = torch.zeros(T, dtype=torch.int64)
+    for e in ends[:-1]:
+        seg[e:] += 1
+    pos = torch.arange(T)
+    mask = ((seg[:, None] != seg[None, :]) | (pos[None, :] > pos[:, None]))[None, None]     # True = masked
+    k = torch.randn(T, 1, HKV, D, generator=g)
+    v = torch.randn(T, 1, HKV, D, generator=g)
+    t0 = time.perf_counter()
+    for h in range(HQ):
+        q = torch.randn(T, 1, 1, D, generator=g)
+        kh = h // (HQ // HKV)
+        A.eager_attention(q, k[:, :, kh:kh + 1], v[:, :, kh:kh + 1], mask, math.sqrt(D))
+    dt = time.perf_counter() - t0
+    return {"tokens_per_s": T / dt, "seconds": dt, "what": "configs[0]: 8192 packed tokens, 5 segments, 40/8 heads, one layer, eager fp32, timed in full"}
 
 
 def profiled_traffic(summary_name, kernel):
@@ -188,12 +211,19 @@ def main():
             from long_vita_amd.ring_context_parallel import RingAttention
             import torch.distributed as dist
             ring = RingAttention(dist.group.WORLD, cp, rank, causal=True)
+            ring.profile = True     # three event records per ring step: where a rank's time goes shows in the bench line
+            ring_steps = []
+
+            def harvest():
+                ring_steps.append(ring.step_stats())
 
             def step():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 ring.forward(q.view(s_loc, 1, HQ * D), k.view(s_loc, 1, HKV * D), v.view(s_loc, 1, HKV * D), HQ, scale)
                 e1.record()
+                e1.synchronize()      # one host wait per step (a real layer would not have it; it costs microseconds of 1 s)
+                harvest()
                 return e0, e1
         tokens_per_step = S
         flops_per_step = causal_fwd_flops([S])
@@ -320,6 +350,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if wl == "prefill_1m" and world > 1:
+        ring_steps.clear()
     barrier(world)
     t0 = time.perf_counter()
     events = [step() for _ in range(args.steps)]
@@ -327,6 +359,17 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, world)
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     mean_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    per_rank = None
+    if wl == "prefill_1m" and world > 1:
+        # every rank's own view: device time per step, and per ring step the block kernels + merge against the time the
+        # compute stream then stood waiting for the next K/V block (zig-zag imbalance and wire time show up there)
+        import torch.distributed as dist
+        n = max(1, len(ring_steps))
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "device_ms_per_step": mean_kernel_s * 1e3,
+                "ring_step_compute_ms": [sum(st[i][0] for st in ring_steps) / n for i in range(cp)],
+                "ring_step_wait_ms": [sum(st[i][1] for st in ring_steps) / n for i in range(cp)]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     mean_kernel_s = max_over_ranks(mean_kernel_s, world)
 
     if rank == 0:
@@ -355,8 +398,19 @@ def main():
                 res["roofline"]["traffic"] = per_call      # per launch of the dominant kernel (16 launches per step)
         if traffic_note:
             res["roofline"]["traffic_note"] = traffic_note
+        if per_rank is not None:
+            import torch.distributed as dist
+            res["n_ranks_seen"] = dist.get_world_size()
+            res["per_rank"] = per_rank
+        try:    # the clock the chip holds under a dense MFMA loop: the peak above assumes 2.4 GHz
+            res["mfma_clock_mhz"] = ops.mfma_clock_mhz(dev)
+        except Exception as e:      # diagnostic only
+            res["mfma_clock_mhz"] = {"error": str(e)}
+        res["host_cpus"] = os.cpu_count()
         if not args.no_cpu_baseline and wl == "prefill_1m":
             res["cpu_baseline"] = cpu_baseline(config["seq_len"])
+            if world == 1 and not args.seq:
+                res["cpu_baseline"]["cfg1_full"] = cpu_baseline_cfg1()
         print(json.dumps(res), flush=True)
     barrier(world)
     if world > 1:

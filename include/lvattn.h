@@ -52,6 +52,13 @@ int lvattn_abi_version(void);
 int lvattn_fwd_block_m(void);
 const char* lvattn_last_error(void);
 
+/* Diagnostic, no counterpart in the reference: the shader clock the chip holds under a dense bf16 MFMA loop (the 2.5
+ * PFLOP/s peak assumes 2.4 GHz).  n_workgroups x 4 waves run `iters` x 4 v_mfma_f32_32x32x16_bf16 on the 1024 bf16
+ * values at `seed` (random data: zeros clock higher) and write, per wave, {shader-clock ticks, ticks of the constant
+ * 100 MHz counter} to stamps[2 * wave ..] (uint64); sink [n_workgroups * 4] floats keeps the arithmetic alive.
+ * clock in MHz = 100 * stamps[2w] / stamps[2w + 1]. */
+int lv_clock_probe(const void* seed, uint64_t* stamps, float* sink, int n_workgroups, int iters, void* stream);
+
 /* ---- host-side block builders (pure CPU, no HIP calls) -------------------
  * cu_seqlens_host = [0] + the reference's `actual_seq_len` cumulative end offsets
  * (lcvlm_modellink/core/transformer/dot_product_attention.py:333,363-364;
@@ -180,6 +187,12 @@ int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk, const floa
                  int row0, int rows, int hq, int d,
                  int64_t blk_row_stride, int64_t blk_head_stride,
                  int64_t lse_stride, void* stream);
+/* The first step of a ring pass: (out_acc, lse_acc) := (out_blk, lse_blk) for the same rows, without reading the
+ * accumulators (they need no zero / -inf fill beforehand). */
+int lvattn_merge_init(float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
+                      int row0, int rows, int hq, int d,
+                      int64_t blk_row_stride, int64_t blk_head_stride,
+                      int64_t lse_stride, void* stream);
 
 /* ---- token compression / indexing --------------------------------------------
  * lv_pixel_shuffle: MegatronVisionModel.forward_once + pixel_shuffle(0.5)

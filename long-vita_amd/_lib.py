@@ -37,6 +37,8 @@ _SIGNATURES = {
                           _f, _int, _int, _vp]),
     "lvattn_cast_f32_bf16": (_int, [_vp, _vp, _int, _int, _int, _i64, _i64, _vp]),
     "lvattn_merge": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _i64, _vp]),
+    "lvattn_merge_init": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _i64, _vp]),
+    "lv_clock_probe": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
     "lv_pixel_shuffle": (_int, [_vp, _vp, _int, _int, _int, _int, _i64, _vp]),
     "lv_scatter_rows": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp]),
     "lv_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),

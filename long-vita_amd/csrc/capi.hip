@@ -354,6 +354,7 @@ extern "C" int lvattn_bwd(const void* q, const void* k, const void* v, const voi
 // ring merge: (out_acc, lse_acc) <- combine with (out_blk, lse_blk)
 // one thread per 8 output elements
 // ---------------------------------------------------------------------------
+template <bool INIT>
 __global__ void lv_merge_kernel(float* __restrict__ out_acc, float* __restrict__ lse_acc,
                                 const __bf16* __restrict__ out_blk, const float* __restrict__ lse_blk,
                                 int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs, int64_t lse_stride) {
@@ -364,24 +365,33 @@ __global__ void lv_merge_kernel(float* __restrict__ out_acc, float* __restrict__
         int64_t rh = idx / cpr;
         int head = (int)(rh % hq);
         int row = row0 + (int)(rh / hq);
-        float la = lse_acc[(int64_t)head * lse_stride + row];
         float lb = lse_blk[(int64_t)head * lse_stride + row];
-        float m = fmaxf(la, lb);
-        float wa = 0.f, wb = 0.f, ln = -INFINITY;
-        if (m > -INFINITY) {
-            float ea = __expf(la - m), eb = __expf(lb - m);
-            float tot = ea + eb;
-            wa = ea / tot; wb = eb / tot;
-            ln = m + __logf(tot);
-        }
         float* oa = out_acc + ((int64_t)row * hq + head) * d + ch * 8;
         const __bf16* ob = out_blk + (int64_t)row * blk_rs + (int64_t)head * blk_hs + ch * 8;
-        f32x4 a0 = *reinterpret_cast<f32x4*>(oa), a1 = *reinterpret_cast<f32x4*>(oa + 4);
         bf16x8 b = *reinterpret_cast<const bf16x8*>(ob);
+        f32x4 a0, a1;
+        float ln;
+        if constexpr (INIT) {   // the block IS the running result so far: the accumulators are never read
+            ln = lb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a0[i] = a0[i] * wa + (float)b[i] * wb;
-            a1[i] = a1[i] * wa + (float)b[i + 4] * wb;
+            for (int i = 0; i < 4; ++i) { a0[i] = (float)b[i]; a1[i] = (float)b[i + 4]; }
+        } else {
+            float la = lse_acc[(int64_t)head * lse_stride + row];
+            float m = fmaxf(la, lb);
+            float wa = 0.f, wb = 0.f;
+            ln = -INFINITY;
+            if (m > -INFINITY) {
+                float ea = __expf(la - m), eb = __expf(lb - m);
+                float tot = ea + eb;
+                wa = ea / tot; wb = eb / tot;
+                ln = m + __logf(tot);
+            }
+            a0 = *reinterpret_cast<f32x4*>(oa); a1 = *reinterpret_cast<f32x4*>(oa + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0[i] = a0[i] * wa + (float)b[i] * wb;
+                a1[i] = a1[i] * wa + (float)b[i + 4] * wb;
+            }
         }
         *reinterpret_cast<f32x4*>(oa) = a0;
         *reinterpret_cast<f32x4*>(oa + 4) = a1;
@@ -392,9 +402,8 @@ __global__ void lv_merge_kernel(float* __restrict__ out_acc, float* __restrict__
     }
 }
 
-extern "C" int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
-                            int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs,
-                            int64_t lse_stride, void* stream) {
+static int merge_impl(bool init, float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
+                      int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs, int64_t lse_stride, void* stream) {
     if (!out_acc || !lse_acc || !out_blk || !lse_blk) return fail(LV_EINVAL, "null pointer");
     // the in-place lse update needs the d/8 threads of a (row, head) inside one wave: d/8 must divide 64
     if (d != 64 && d != 128) return fail(LV_EINVAL, "lvattn_merge: head dim %d not supported (64 or 128)", d);
@@ -404,9 +413,25 @@ extern "C" int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk,
     if (rows == 0) return LV_OK;
     int64_t total = (int64_t)rows * hq * (d / 8);
     int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(lv_merge_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_acc, lse_acc,
-                       (const __bf16*)out_blk, lse_blk, row0, rows, hq, d, blk_rs, blk_hs, lse_stride);
+    if (init)
+        hipLaunchKernelGGL(lv_merge_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_acc, lse_acc,
+                           (const __bf16*)out_blk, lse_blk, row0, rows, hq, d, blk_rs, blk_hs, lse_stride);
+    else
+        hipLaunchKernelGGL(lv_merge_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, out_acc, lse_acc,
+                           (const __bf16*)out_blk, lse_blk, row0, rows, hq, d, blk_rs, blk_hs, lse_stride);
     return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "merge launch failed");
+}
+
+extern "C" int lvattn_merge(float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
+                            int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs,
+                            int64_t lse_stride, void* stream) {
+    return merge_impl(false, out_acc, lse_acc, out_blk, lse_blk, row0, rows, hq, d, blk_rs, blk_hs, lse_stride, stream);
+}
+
+extern "C" int lvattn_merge_init(float* out_acc, float* lse_acc, const void* out_blk, const float* lse_blk,
+                                 int row0, int rows, int hq, int d, int64_t blk_rs, int64_t blk_hs,
+                                 int64_t lse_stride, void* stream) {
+    return merge_impl(true, out_acc, lse_acc, out_blk, lse_blk, row0, rows, hq, d, blk_rs, blk_hs, lse_stride, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -528,6 +553,46 @@ extern "C" int lv_gather_rows(const void* src, void* dst, const int64_t* index, 
                               int64_t row_bytes, int64_t src_rows, void* stream) {
     if (!index) return fail(LV_EINVAL, "index is null");
     return move_rows(src, dst, index, nullptr, n, row_bytes, src_rows, n, stream);
+}
+
+// ---------------------------------------------------------------------------
+// shader-clock probe: what clock does the chip hold under a dense bf16 MFMA loop on the caller's (random) data?
+// Every wave stamps the shader-clock counter and the constant 100 MHz counter around its loop;
+// clock = d(shader counter) / d(100 MHz counter) * 100 MHz.  Diagnostic only: no product kernel carries stamps.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lv_clock_probe_kernel(const __bf16* __restrict__ seed, uint64_t* __restrict__ stamps,
+                                                            float* __restrict__ sink, int iters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(seed + 8 * lane);
+    bf16x8 b = *reinterpret_cast<const bf16x8*>(seed + 8 * (64 + lane));
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) keep += acc[j][0] + acc[j][15];
+    asm volatile("" : "+v"(keep));
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+        stamps[2 * wave] = t1 - t0;
+        stamps[2 * wave + 1] = r1 - r0;
+        sink[wave] = keep;
+    }
+}
+
+extern "C" int lv_clock_probe(const void* seed, uint64_t* stamps, float* sink, int n_workgroups, int iters, void* stream) {
+    if (!seed || !stamps || !sink) return fail(LV_EINVAL, "lv_clock_probe: null pointer");
+    if (((uintptr_t)seed & 15) || n_workgroups <= 0 || iters <= 0) return fail(LV_EINVAL, "lv_clock_probe: bad argument");
+    hipLaunchKernelGGL(lv_clock_probe_kernel, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, (const __bf16*)seed, stamps, sink, iters);
+    return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "lv_clock_probe: launch failed");
 }
 
 // ---------------------------------------------------------------------------

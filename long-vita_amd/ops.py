@@ -241,10 +241,12 @@ def cast_f32_to_bf16(src: torch.Tensor, dst: torch.Tensor | None = None) -> torc
     return dst
 
 
-def merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0: int, rows: int):
-    """In-place log-sum-exp merge of a block result into the running fp32 result."""
+def merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0: int, rows: int, init: bool = False):
+    """In-place log-sum-exp merge of a block result into the running fp32 result; with ``init`` the block becomes
+    the running result for those rows (the accumulators are not read)."""
     _, hq, d = out_acc.shape
-    check(_lib.lib().lvattn_merge(_ptr(out_acc), _ptr(lse_acc), _ptr(out_blk), _ptr(lse_blk), row0, rows, hq, d,
+    fn = _lib.lib().lvattn_merge_init if init else _lib.lib().lvattn_merge
+    check(fn(_ptr(out_acc), _ptr(lse_acc), _ptr(out_blk), _ptr(lse_blk), row0, rows, hq, d,
                                   out_blk.stride(0), out_blk.stride(1), lse_acc.stride(0), _stream()), "lvattn_merge")
 
 
@@ -759,3 +761,23 @@ def embed_tokens(proj: torch.Tensor, conv_bias: torch.Tensor, class_token: torch
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (proj, conv_bias, class_token, pos_emb)):
         return _EmbedTokens.apply(proj, conv_bias, class_token, pos_emb)
     return embed_tokens_launch(proj, conv_bias, class_token, pos_emb)
+
+
+# ---------------------------------------------------------------------------
+# diagnostics
+# ---------------------------------------------------------------------------
+def mfma_clock_mhz(device=None, milliseconds: float = 40.0) -> dict:
+    """Shader clock (MHz) the chip holds under a dense bf16 MFMA loop on random data, from in-kernel stamps of the
+    shader-clock counter against the constant 100 MHz counter: median, min and max over all waves."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    n_wg = 2 * torch.cuda.get_device_properties(device).multi_processor_count
+    iters = max(1, int(milliseconds * 1e-3 * 2.0e9 / 128 / 2))      # 4 MFMAs of 32 cycles per iteration, two workgroups per CU
+    seed = torch.randn(1024, device=device).to(torch.bfloat16)
+    stamps = torch.zeros((n_wg * 4, 2), dtype=torch.int64, device=device)
+    sink = torch.empty(n_wg * 4, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(_lib.lib().lv_clock_probe(_ptr(seed), _ptr(stamps), _ptr(sink), n_wg, iters, _stream()), "lv_clock_probe")
+        torch.cuda.synchronize()
+    st = stamps.cpu().double()
+    mhz = 100.0 * st[:, 0] / st[:, 1].clamp(min=1)
+    return {"median": float(mhz.median()), "min": float(mhz.min()), "max": float(mhz.max()), "waves": int(mhz.numel())}

@@ -51,15 +51,15 @@ class HipBackend:
         desc_k = self.ops.rects_blocks_on_device(rects, True, q3.device)
         self.ops.attn_bwd_launch(q3, k3, v3, out3, dout3, lse, desc_q, desc_k, scale, True, dq_acc, dk_acc, dv_acc, delta, True)
 
-    def merge(self, out_acc, lse_acc, out_blk, lse_blk, row0, rows):
-        self.ops.merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0, rows)
+    def merge(self, out_acc, lse_acc, out_blk, lse_blk, row0, rows, init=False):
+        self.ops.merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0, rows, init)
 
-    def finalize(self, out_acc):
-        return self.ops.cast_f32_to_bf16(out_acc)
+    def finalize(self, out_acc, out=None):
+        return self.ops.cast_f32_to_bf16(out_acc, out)
 
-    def delta(self, out3, dout3, lse):
-        o = self.ops
-        delta = torch.empty_like(lse)
+    def delta(self, out3, dout3, lse, delta=None):
+        if delta is None:
+            delta = torch.empty_like(lse)
         from ._lib import lib, check
         check(lib().lvattn_bwd_delta(out3.data_ptr(), dout3.data_ptr(), delta.data_ptr(), out3.shape[0], out3.shape[1],
                                      out3.shape[2], out3.stride(0), out3.stride(1), dout3.stride(0), dout3.stride(1),
@@ -125,6 +125,25 @@ class RingAttention:
         self.global_ranks = list(global_ranks) if global_ranks is not None else list(range(self.cp))
         self.backend = backend
         self.comm = comm
+        self._ws: dict = {}        # buffers of forward / backward, allocated once per shape
+        self.profile = False       # record per-step device timestamps into self.timeline (forward)
+        self.timeline: list = []
+
+    def _buffers(self, key, make):
+        """Per-engine workspace: every buffer of a pass is allocated the first time its shape is seen and reused by
+        every later call (a caching allocator under RCCL traffic can synchronise; a steady-state step allocates
+        nothing).  A result that leaves the engine is the caller's from then on, so those are allocated per call."""
+        hit = self._ws.get(key)
+        if hit is None:
+            if len(self._ws) >= 4:             # a shape change (new sequence length) retires the oldest set
+                self._ws.pop(next(iter(self._ws)))
+            hit = self._ws[key] = make()
+        return hit
+
+    def step_stats(self):
+        """After a profiled forward and a device synchronisation: milliseconds per ring step as a list of
+        (block kernels + merge, compute stream stalled waiting for the K/V block of the next step)."""
+        return [(a.elapsed_time(b), b.elapsed_time(c)) for a, b, c in self.timeline]
 
     # -- helpers -----------------------------------------------------------
     def _be(self):
@@ -205,24 +224,39 @@ class RingAttention:
         if self.causal and s_loc % 2:
             raise ValueError("zig-zag ring attention needs an even local sequence length")
         q3 = q.reshape(s_loc, b * n_heads, d)
-        kv = [torch.stack([k.reshape(s_loc, b * hkv, d), v.reshape(s_loc, b * hkv, d)]), None]
-        if self.cp > 1:
-            kv[1] = torch.empty_like(kv[0])
-        out_acc = torch.zeros((s_loc, b * n_heads, d), dtype=torch.float32, device=q.device)
-        lse_acc = torch.full((b * n_heads, s_loc), float("-inf"), dtype=torch.float32, device=q.device)
-        out_blk = torch.empty((s_loc, b * n_heads, d), dtype=q.dtype, device=q.device)
-        lse_blk = torch.empty_like(lse_acc)
-        side = self._comm(q.device)
+        dev, cp = q.device, self.cp
+
+        def make():
+            w = {"kv": [torch.empty((2, s_loc, b * hkv, d), dtype=k.dtype, device=dev) for _ in range(2 if cp > 1 else 1)],
+                 "out_acc": torch.empty((s_loc, b * n_heads, d), dtype=torch.float32, device=dev),
+                 "out_blk": torch.empty((s_loc, b * n_heads, d), dtype=q.dtype, device=dev),
+                 "lse_blk": torch.empty((b * n_heads, s_loc), dtype=torch.float32, device=dev)}
+            return w
+        w = self._buffers(("fwd", s_loc, b, n_heads, hkv, d, q.dtype, str(dev)), make)
+        kv, out_acc, out_blk, lse_blk = w["kv"], w["out_acc"], w["out_blk"], w["lse_blk"]
+        # K and V of this rank as ONE message [2, s, Hkv, d]
+        kv[0][0].copy_(k.reshape(s_loc, b * hkv, d))
+        kv[0][1].copy_(v.reshape(s_loc, b * hkv, d))
+        lse_acc = torch.empty((b * n_heads, s_loc), dtype=torch.float32, device=dev)   # returned (saved for backward)
+        packed = cu_seqlens is not None
+        if packed:      # rows are first touched by different chunk pairs: start from the neutral element
+            out_acc.zero_()
+            lse_acc.fill_(float("-inf"))
+        side = self._comm(dev)
         nxt, prv = self._peers()
-        for step in range(self.cp):
-            cur, oth = kv[step % 2], kv[(step + 1) % 2]
+        timeline = []
+        for step in range(cp):
+            cur = kv[step % 2] if cp > 1 else kv[0]
             handle = None
-            if step + 1 < self.cp:
-                handle = side.exchange([cur], [oth], nxt, prv)
-            if cu_seqlens is None:
+            if step + 1 < cp:
+                handle = side.exchange([cur], [kv[(step + 1) % 2]], nxt, prv)
+            if self.profile:
+                t0 = torch.cuda.Event(enable_timing=True); t0.record()
+            if not packed:
                 qr, kr, causal, shift = self.step_rect(step, s_loc)
                 be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk)
-                be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1])
+                # step 0 covers every local row: it initialises the running result instead of merging into it
+                be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1], init=(step == 0))
             else:
                 for rects in self.segment_rects(step, s_loc, cu_seqlens):
                     if rects:
@@ -230,8 +264,15 @@ class RingAttention:
                         lo = min(r[0] for r in rects)
                         hi = max(r[0] + r[1] for r in rects)
                         be.merge(out_acc, lse_acc, out_blk, lse_blk, lo, hi - lo)
+            if self.profile:
+                t1 = torch.cuda.Event(enable_timing=True); t1.record()
             if handle is not None:
                 side.wait(handle)
+            if self.profile:
+                t2 = torch.cuda.Event(enable_timing=True); t2.record()
+                timeline.append((t0, t1, t2))
+        if self.profile:
+            self.timeline = timeline
         out = be.finalize(out_acc).reshape(s_loc, b, hq_d)
         if return_state:
             return out, lse_acc
@@ -249,48 +290,59 @@ class RingAttention:
         q3 = q.reshape(s_loc, b * n_heads, d)
         out3 = out.reshape(s_loc, b * n_heads, d)
         dout3 = dout.reshape(s_loc, b * n_heads, d)
-        delta = be.delta(out3, dout3, lse)
-        kv = [torch.stack([k.reshape(s_loc, b * hkv, d), v.reshape(s_loc, b * hkv, d)]), None]
-        # dK/dV of a K/V block is the sum of one contribution per rank; the running sum follows the
-        # block round the ring.  Each step computes the local contribution into `dloc` while the sum for
-        # this block is still arriving from the previous rank, then adds and forwards: the fp32
-        # accumulator traffic (twice the K/V bytes) overlaps the block kernels as the K/V traffic does.
-        dloc = torch.empty((2, s_loc, b * hkv, d), dtype=torch.float32, device=q.device)
-        dbuf = [None, None]
-        if self.cp > 1:
-            kv[1] = torch.empty_like(kv[0])
-            dbuf = [torch.empty_like(dloc), torch.empty_like(dloc)]
-        dq_acc = torch.zeros((s_loc, b * n_heads, d), dtype=torch.float32, device=q.device)
-        side = self._comm(q.device)
+        dev, cp = q.device, self.cp
+
+        def make():
+            f32 = dict(dtype=torch.float32, device=dev)
+            return {"kv": [torch.empty((2, s_loc, b * hkv, d), dtype=k.dtype, device=dev) for _ in range(2 if cp > 1 else 1)],
+                    # dK/dV of a K/V block is the sum of one contribution per rank; the running sum follows the block
+                    # round the ring.  Each step computes the local contribution into `dloc` while the sum for this
+                    # block is still arriving from the previous rank, then adds and forwards: the fp32 accumulator
+                    # traffic (twice the K/V bytes) overlaps the block kernels as the K/V traffic does.
+                    "dloc": torch.empty((2, s_loc, b * hkv, d), **f32),
+                    "dbuf": [torch.empty((2, s_loc, b * hkv, d), **f32) for _ in range(2)] if cp > 1 else [None, None],
+                    "dq_acc": torch.empty((s_loc, b * n_heads, d), **f32),
+                    "delta": torch.empty((b * n_heads, s_loc), **f32)}
+        w = self._buffers(("bwd", s_loc, b, n_heads, hkv, d, q.dtype, str(dev)), make)
+        kv, dloc, dbuf, dq_acc = w["kv"], w["dloc"], w["dbuf"], w["dq_acc"]
+        delta = be.delta(out3, dout3, lse, w["delta"])
+        kv[0][0].copy_(k.reshape(s_loc, b * hkv, d))
+        kv[0][1].copy_(v.reshape(s_loc, b * hkv, d))
+        dq_acc.zero_()
+        side = self._comm(dev)
         nxt, prv = self._peers()
         pending = None   # exchange of the running sum started at the end of the previous step
-        for step in range(self.cp):
-            cur, oth = kv[step % 2], kv[(step + 1) % 2]
+        for step in range(cp):
+            cur = kv[step % 2] if cp > 1 else kv[0]
             handle = None
-            if step + 1 < self.cp:
-                handle = side.exchange([cur], [oth], nxt, prv)   # K/V travels ahead of the math
-            dloc.zero_()
+            if step + 1 < cp:
+                handle = side.exchange([cur], [kv[(step + 1) % 2]], nxt, prv)   # K/V travels ahead of the math
             if cu_seqlens is None:
                 qr, kr, causal, shift = self.step_rect(step, s_loc)
+                touched = dloc[:, kr[0]:kr[0] + kr[1]]     # the step writes these key rows only: clear and add just them
+                touched.zero_()
                 be.block_bwd(q3, cur[0], cur[1], out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dloc[0], dloc[1])
             else:
+                kr = (0, s_loc)
+                dloc.zero_()
                 for rects in self.segment_rects(step, s_loc, cu_seqlens):   # one launch per chunk pair: no shared rows
                     if rects:
                         self._bwd_rects(be, q3, cur[0], cur[1], out3, dout3, lse, delta, rects, scale, dq_acc, dloc[0], dloc[1])
             if handle is not None:
                 side.wait(handle)
-            if self.cp > 1:
+            if cp > 1:
                 send = dbuf[(step + 1) % 2]
+                ks = slice(kr[0], kr[0] + kr[1])
                 if pending is not None:
                     side.wait(pending)      # `send` now holds the sum so far for this block, from the previous rank
-                    send.add_(dloc)
-                else:
+                    send[:, ks].add_(dloc[:, ks])
+                else:                       # step 0 touches every key row of the local block
                     send.copy_(dloc)
                 # after the last step this hop returns the finished sum to the block's owner
                 pending = side.exchange([send], [dbuf[step % 2]], nxt, prv)
-        if self.cp > 1:
+        if cp > 1:
             side.wait(pending)
-            final = dbuf[(self.cp - 1) % 2]
+            final = dbuf[(cp - 1) % 2]
         else:
             final = dloc
         dq = be.cast(dq_acc, q.dtype).reshape(s_loc, b, hq_d)

@@ -31,16 +31,20 @@ class CheckerBackend:
         out_blk[qr[0]:qr[0] + qr[1]] = torch.from_numpy(o).to(out_blk.dtype)
         lse_blk[:, qr[0]:qr[0] + qr[1]] = torch.from_numpy(l).to(lse_blk.dtype)
 
-    def merge(self, out_acc, lse_acc, out_blk, lse_blk, row0, rows):
+    def merge(self, out_acc, lse_acc, out_blk, lse_blk, row0, rows, init=False):
         sl = slice(row0, row0 + rows)
+        if init:        # the accumulators hold nothing yet (and may hold anything)
+            out_acc[sl] = out_blk[sl].to(out_acc.dtype)
+            lse_acc[:, sl] = lse_blk[:, sl]
+            return
         o, l = A.merge_blocks(out_acc[sl], lse_acc[:, sl], out_blk[sl], lse_blk[:, sl])
         out_acc[sl] = torch.from_numpy(o).to(out_acc.dtype)
         lse_acc[:, sl] = torch.from_numpy(l).to(lse_acc.dtype)
 
-    def finalize(self, out_acc):
+    def finalize(self, out_acc, out=None):
         return out_acc.clone()
 
-    def delta(self, out3, dout3, lse):
+    def delta(self, out3, dout3, lse, delta=None):
         return (out3.double() * dout3.double()).sum(-1).t().contiguous().to(lse.dtype)
 
     def block_bwd(self, q3, k3, v3, out3, dout3, lse, delta, qr, kr, causal, shift, scale, dq_acc, dk_acc, dv_acc):
