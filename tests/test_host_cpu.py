@@ -148,3 +148,75 @@ def test_flash_attention_forward_branch_errors():
     finally:
         state.mpu.initialize(None, 1, 0)
         state.set_actual_seq_len(None)
+
+
+def _fake_target_modules(monkeypatch):
+    """Empty modules at the five dotted paths the adaptor patches (Megatron / ModelLink / MindSpeed are not installed)."""
+    import sys
+    import types
+    made = {}
+    for dotted in ("modellink.core.transformer.dot_product_attention",
+                   "mindspeed.core.context_parallel.ring_context_parallel",
+                   "megatron.core.models.common.embeddings.rotary_pos_embedding"):
+        parts = dotted.split(".")
+        for i in range(1, len(parts) + 1):
+            name = ".".join(parts[:i])
+            if name not in made:
+                m = types.ModuleType(name)
+                m.__path__ = []
+                made[name] = m
+                monkeypatch.setitem(sys.modules, name, m)
+                if i > 1:
+                    setattr(made[".".join(parts[:i - 1])], parts[i - 1], m)
+    return made
+
+
+def test_register_patches_hits_the_dotted_names(monkeypatch):
+    """The adaptor registers its five functions under the dotted names the reference patches
+    (lcvlm_modellink/megatron_adaptor.py:11-13, 92-93) and a manager that applies by dotted name lands them there."""
+    from long_vita_amd import host_standins, megatron_adaptor as M
+    made = _fake_target_modules(monkeypatch)
+    monkeypatch.setattr(host_standins.PatchesManager, "patches_info", {})
+    names = M.register_patches(host_standins.PatchesManager)
+    assert len(names) == 5 and set(names) == set(M.PATCHES)
+    applied = host_standins.PatchesManager.apply_patches()
+    assert set(applied) == set(names)
+    dpa = made["modellink.core.transformer.dot_product_attention"]
+    assert dpa.flash_attention_forward is M.flash_attention_forward
+    assert dpa.do_ring_context_parallel is M.do_ring_context_parallel
+    assert made["mindspeed.core.context_parallel.ring_context_parallel"].ringattn_context_parallel is M.ringattn_context_parallel
+    rot = made["megatron.core.models.common.embeddings.rotary_pos_embedding"]
+    assert rot.RotaryEmbedding is M.RotaryEmbedding and rot.apply_rotary_pos_emb is M.apply_rotary_pos_emb
+
+    class TwoArgManager:            # a manager without the force_patch keyword is served too
+        seen = []
+
+        @classmethod
+        def register_patch(cls, name, fn):
+            cls.seen.append(name)
+    M.register_patches(TwoArgManager)
+    assert TwoArgManager.seen == list(M.PATCHES)
+
+
+def test_host_standins_serve_the_reference_imports(monkeypatch):
+    """`from mindspeed.utils import set_actual_seq_len ...` (training/utils.py:29) and the other Ascend-only imports of
+    the path resolve to this package's state once the stand-ins are installed."""
+    import sys
+    from long_vita_amd import host_standins, state
+    for name in [n for n in sys.modules if n == "mindspeed" or n.startswith("mindspeed.")]:
+        monkeypatch.delitem(sys.modules, name)
+    installed = host_standins.install()
+    try:
+        assert "mindspeed.utils" in installed and "mindspeed.patch_utils" in installed
+        from mindspeed.utils import compute_actual_seq_len, get_actual_seq_len, set_actual_seq_len, set_position_ids  # noqa: F401
+        from mindspeed.patch_utils import MindSpeedPatchesManager
+        from mindspeed.core.context_parallel.ring_context_parallel import ringattn_context_parallel  # noqa: F401
+        set_actual_seq_len([3, 8])
+        assert state.get_actual_seq_len() == [3, 8] and get_actual_seq_len() == [3, 8]
+        assert MindSpeedPatchesManager is host_standins.PatchesManager
+        pos = torch.tensor([[0, 1, 2, 0, 1, 0, 1, 2]])
+        assert compute_actual_seq_len(pos) == [3, 5, 8]
+    finally:
+        state.set_actual_seq_len(None)
+        for name in installed:
+            sys.modules.pop(name, None)
