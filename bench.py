@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "vit_tower", "rope_qk", "decode"])
+    ap.add_argument("--workload", default="prefill_1m", choices=["prefill_1m", "cfg3_fwd_bwd", "cfg3_packed", "cfg2_vit", "vit_tower", "rope_qk", "rope_fused", "decode"])
     ap.add_argument("--seq", type=int, default=0, help="override the sequence length (testing)")
     ap.add_argument("--heads", default="", help="override 'q_heads,kv_heads' (testing; e.g. 5,1 = one rank's share under TP=8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -284,6 +284,44 @@ def main():
         flops_per_step = flops_per_gpu_step = 0.0
         config = {"workload": "rope_qk: rotary embedding of Q [S,40,128] and K [S,8,128], in place", "seq_len": S}
         scaling = "weak"
+    elif wl == "rope_fused":  # rotary embedding + causal forward at 128K: rotation of q inside the attention kernel vs as its own pass
+        S = args.seq or 131072
+        q, k, v = rnd(S, HQ, D), rnd(S, HKV, D), rnd(S, HKV, D)
+        inv = 1.0 / (1000000 ** (torch.arange(0, D, 2, dtype=torch.float32, device=dev) / D))
+        ang = torch.outer(torch.arange(S, device=dev, dtype=torch.float32), inv)
+        ang = torch.cat((ang, ang), -1)
+        cos_t, sin_t = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+        scale = 1.0 / math.sqrt(D)
+        desc = ops.blocks_on_device([0, S], True, False, dev)
+        out = torch.empty_like(q)
+        lse = torch.empty((HQ, S), dtype=torch.float32, device=dev)
+        q_rot, k_rot = torch.empty_like(q), torch.empty_like(k)
+
+        def two_pass():
+            ops.rope_launch(q, cos_t, sin_t, out=q_rot)
+            ops.rope_launch(k, cos_t, sin_t, out=k_rot)
+            ops.attn_fwd_launch(q_rot, k_rot, v, desc, scale, True, out, lse)
+
+        def step():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.rope_launch(k, cos_t, sin_t, out=k_rot)
+            ops.attn_fwd_rope_launch(q, k_rot, v, desc, scale, True, cos_t, sin_t, out=out, lse=lse)
+            e1.record()
+            return e0, e1
+        two_pass()
+        ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ta.record()
+        for _ in range(5):
+            two_pass()
+        tb.record()
+        torch.cuda.synchronize()
+        extra["two_pass_ms"] = ta.elapsed_time(tb) / 5
+        tokens_per_step = S
+        flops_per_step = flops_per_gpu_step = causal_fwd_flops([S])
+        config = {"workload": "rope_fused: rotary embedding of K (own pass) + causal forward that rotates Q as it loads it, one 128K segment",
+                  "seq_len": S, "q_heads": HQ, "kv_heads": HKV, "head_dim": D, "parallelism": "cp1"}
+        scaling = "weak"
     elif wl == "decode":  # one new token against a 1M-token KV cache, one layer (bandwidth-bound: the cache is read once)
         S = args.seq or 1048576
         q, kc, vc = rnd(1, HQ, D), rnd(1, S, HKV, D), rnd(1, S, HKV, D)
@@ -398,6 +436,7 @@ def main():
                 res["roofline"]["traffic"] = per_call      # per launch of the dominant kernel (16 launches per step)
         if traffic_note:
             res["roofline"]["traffic_note"] = traffic_note
+        res.update(extra)
         if per_rank is not None:
             import torch.distributed as dist
             res["n_ranks_seen"] = dist.get_world_size()

@@ -228,6 +228,28 @@ int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, 
             int64_t rows, int heads, int d, int rot,
             int64_t x_row_stride, int64_t x_head_stride, int64_t o_row_stride, int64_t o_head_stride,
             int64_t tab_rows, int tab_div, int conj, void* stream);
+/* The rotation folded into the attention path (the scripts' --use-fused-rotary-pos-emb,
+ * scripts/modellink/qwen25/finetune_qwen25_14b_intern_300m_ptd_tp8pp1_stage4.sh:164, removes the same pass on the NPU):
+ *  - lvattn_fwd_rope = lvattn_fwd on UNROTATED queries: each workgroup rotates its query rows in registers as it
+ *    loads them (same tables, table-row rule and bf16 roundings as lv_rope with rot == d, so the result equals
+ *    lvattn_fwd on lv_rope(q) bit for bit); k must already be rotated.  q_rot (optional, [q rows, hq, d] bf16 with
+ *    strides) receives the rotated queries for the backward pass.  Head dim 128 only.
+ *  - lv_rope_pack_kv rotates K while packing K and V into the ring's message buffer kv [2, rows, heads, d]
+ *    (contiguous): kv[0] = lv_rope(k), kv[1] = v -- one pass instead of a rotation and two copies. */
+int lvattn_fwd_rope(const void* q, const void* k, const void* v, void* out, float* lse,
+                    const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
+                    int hq, int hkv, int d,
+                    int64_t q_row_stride, int64_t q_head_stride,
+                    int64_t k_row_stride, int64_t k_head_stride,
+                    int64_t v_row_stride, int64_t v_head_stride,
+                    int64_t o_row_stride, int64_t o_head_stride,
+                    int64_t lse_stride, float softmax_scale, int causal,
+                    const void* cos_tab, const void* sin_tab, const int32_t* pos_ids, int64_t tab_rows, int tab_div,
+                    void* q_rot, int64_t q_rot_row_stride, int64_t q_rot_head_stride, void* stream);
+int lv_rope_pack_kv(const void* k, const void* v, void* kv, const void* cos_tab, const void* sin_tab,
+                    const int32_t* pos_ids, int64_t rows, int heads, int d, int rot,
+                    int64_t k_row_stride, int64_t k_head_stride, int64_t v_row_stride, int64_t v_head_stride,
+                    int64_t tab_rows, int tab_div, void* stream);
 
 /* ---- InternViT encoder pieces around its GEMMs --------------------------------------
  * The reference builds the tower from Megatron modules (lcvlm_modellink/core/models/vision/vit_layer_specs.py:80-103:

@@ -59,6 +59,10 @@ _SIGNATURES = {
     "lv_patchify": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "lv_embed_tokens": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "lv_rope": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
+    "lvattn_fwd_rope": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
+                               _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int,
+                               _vp, _vp, _vp, _i64, _int, _vp, _i64, _i64, _vp]),
+    "lv_rope_pack_kv": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

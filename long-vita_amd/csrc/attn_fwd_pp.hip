@@ -45,7 +45,7 @@ __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t rs, int voff, ui
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool ROPE = false>
 __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
     constexpr int BN = 64;            // keys per tile
     constexpr int KS = D / 16;        // k-steps of the QK^T product
@@ -106,6 +106,33 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
     bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qptr + 16 * ks);
+    if constexpr (ROPE) {
+        // Rotary embedding of the query row on the lane: column c pairs with c + D/2, i.e. fragment ks with ks + KS/2
+        // of the same lane.  The cos / sin row comes in with the same addressing as the query row; the op order and
+        // the bf16 roundings are those of lv_rope_kernel, so the rotated row is bit-identical to the standalone pass.
+        int64_t trow = p.rope_pos ? (int64_t)p.rope_pos[q_row] : (int64_t)q_row / p.rope_tab_div;
+        trow = trow < 0 ? 0 : (trow >= p.rope_tab_rows ? p.rope_tab_rows - 1 : trow);
+        const __bf16* cp = p.rope_cos + trow * D + 8 * h;
+        const __bf16* sp = p.rope_sin + trow * D + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) {
+            const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(cp + 16 * ks), c2 = *reinterpret_cast<const bf16x8*>(cp + 16 * ks + D / 2);
+            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(sp + 16 * ks), s2 = *reinterpret_cast<const bf16x8*>(sp + 16 * ks + D / 2);
+            const bf16x8 x1 = qf[ks], x2 = qf[ks + KS / 2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r1, r2;
+                rope_pair<false>((float)x1[e], (float)x2[e], (float)c1[e], (float)s1[e], (float)c2[e], (float)s2[e], r1, r2);
+                qf[ks][e] = as_bf16(rb(r1));
+                qf[ks + KS / 2][e] = as_bf16(rb(r2));
+            }
+        }
+        if (p.q_rot && qi < q_rows) {   // the rotated queries, for the backward pass
+            __bf16* qr = p.q_rot + (int64_t)q_row * p.qr_rs + (int64_t)head * p.qr_hs + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(qr + 16 * ks) = qf[ks];
+        }
+    }
 
     int limit = qi + shift;  // visible keys (relative to k_row0) for this lane's row: j <= limit
     if (limit > k_len - 1 || qi >= q_rows) limit = k_len - 1;
@@ -372,11 +399,19 @@ static void launch_pp(const FwdParams& p, int causal, hipStream_t stream) {
     dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(512);
 #endif
     size_t lds = (size_t)3 * 2 * 64 * D * 2;  // 3 slots x (K tile + V tile)
+    if constexpr (D == 128) {
+        if (p.rope_cos) {
+            if (causal) hipLaunchKernelGGL((lv_fwd_pp_kernel<D, true, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((lv_fwd_pp_kernel<D, false, true>), grid, block, lds, stream, p);
+            return;
+        }
+    }
     if (causal) hipLaunchKernelGGL((lv_fwd_pp_kernel<D, true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((lv_fwd_pp_kernel<D, false>), grid, block, lds, stream, p);
 }
 
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream) {
+    if (p.rope_cos && d != 128) return -3;   // the fused rotation exists for head dim 128 only
     if (d == 128) launch_pp<128>(p, causal, stream);
     else launch_pp<64>(p, causal, stream);
     return hipGetLastError() == hipSuccess ? 0 : -2;

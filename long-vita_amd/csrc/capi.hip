@@ -178,11 +178,21 @@ static int check_common(const void* q, const void* k, const void* v, int hq, int
     return 0;
 }
 
-extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
-                          const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
-                          int hq, int hkv, int d,
-                          int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
-                          int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream) {
+struct RopeArgs {
+    const void* cos_tab = nullptr;
+    const void* sin_tab = nullptr;
+    const int32_t* pos_ids = nullptr;
+    int64_t tab_rows = 0;
+    int tab_div = 1;
+    void* q_rot = nullptr;
+    int64_t qr_rs = 0, qr_hs = 0;
+};
+
+static int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
+                    const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
+                    int hq, int hkv, int d,
+                    int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                    int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream, const RopeArgs* rope) {
     if (int e = check_common(q, k, v, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
     if (!out || !lse || !desc_dev) return fail(LV_EINVAL, "null out/lse/desc pointer");
     if (((uintptr_t)out & 7) || (o_rs & 3) || (o_hs & 3)) return fail(LV_EINVAL, "out must be 8-byte aligned with strides % 4 == 0");
@@ -190,7 +200,7 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
     if (lse_stride < q_rows_total) return fail(LV_EINVAL, "lse_stride %lld < q_rows_total %d", (long long)lse_stride, q_rows_total);
     if (n_blocks == 0) return LV_OK;
     if ((int64_t)n_blocks * hq > 0x7fffffffLL) return fail(LV_EINVAL, "grid too large");
-    FwdParams p;
+    FwdParams p{};
     p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.o = (__bf16*)out; p.lse = lse;
     p.desc = (const AttnDesc*)desc_dev;
     p.n_blocks = n_blocks; p.hq = hq; p.hkv = hkv; p.group = hq / hkv;
@@ -198,11 +208,51 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
     p.q_rs = q_rs; p.q_hs = q_hs; p.k_rs = k_rs; p.k_hs = k_hs; p.v_rs = v_rs; p.v_hs = v_hs;
     p.o_rs = o_rs; p.o_hs = o_hs; p.lse_stride = lse_stride;
     p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+    if (rope) {
+        // the rotation lives in the ping-pong kernel (head dim 128), whatever kernel is selected for plain launches
+        if (d != 128) return fail(LV_EINVAL, "lvattn_fwd_rope: head dim %d (the fused rotation needs 128)", d);
+        if (fwd_waves() != 8) return fail(LV_EINVAL, "lvattn_fwd_rope: needs 256-row work items (LVATTN_FWD_WAVES=4 is set)");
+        if (!rope->cos_tab || !rope->sin_tab) return fail(LV_EINVAL, "lvattn_fwd_rope: null cos / sin table");
+        if (((uintptr_t)rope->cos_tab | (uintptr_t)rope->sin_tab | (uintptr_t)rope->q_rot) & 15)
+            return fail(LV_EINVAL, "lvattn_fwd_rope: tables and q_rot must be 16-byte aligned");
+        if (rope->tab_rows <= 0 || rope->tab_div <= 0) return fail(LV_EINVAL, "lvattn_fwd_rope: tab_rows=%lld tab_div=%d", (long long)rope->tab_rows, rope->tab_div);
+        if (!rope->pos_ids && (int64_t)(q_rows_total - 1) / rope->tab_div >= rope->tab_rows)
+            return fail(LV_EINVAL, "lvattn_fwd_rope: %d rows / %d need more than the table's %lld rows", q_rows_total, rope->tab_div, (long long)rope->tab_rows);
+        if (rope->q_rot && ((rope->qr_rs | rope->qr_hs) & 7)) return fail(LV_EINVAL, "lvattn_fwd_rope: q_rot strides must be multiples of 8 elements");
+        p.rope_cos = (const __bf16*)rope->cos_tab; p.rope_sin = (const __bf16*)rope->sin_tab; p.rope_pos = rope->pos_ids;
+        p.rope_tab_rows = rope->tab_rows; p.rope_tab_div = rope->tab_div;
+        p.q_rot = (__bf16*)rope->q_rot; p.qr_rs = rope->qr_rs; p.qr_hs = rope->qr_hs;
+        if (lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return LV_OK;
+    }
     const int rc = fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
                    : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
                                      : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream);
     if (rc) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
+}
+
+extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                          const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
+                          int hq, int hkv, int d,
+                          int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                          int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream) {
+    return fwd_impl(q, k, v, out, lse, desc_dev, n_blocks, q_rows_total, k_rows_total, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs,
+                    o_rs, o_hs, lse_stride, scale, causal, stream, nullptr);
+}
+
+extern "C" int lvattn_fwd_rope(const void* q, const void* k, const void* v, void* out, float* lse,
+                               const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
+                               int hq, int hkv, int d,
+                               int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                               int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal,
+                               const void* cos_tab, const void* sin_tab, const int32_t* pos_ids, int64_t tab_rows, int tab_div,
+                               void* q_rot, int64_t qr_rs, int64_t qr_hs, void* stream) {
+    RopeArgs r;
+    r.cos_tab = cos_tab; r.sin_tab = sin_tab; r.pos_ids = pos_ids; r.tab_rows = tab_rows; r.tab_div = tab_div;
+    r.q_rot = q_rot; r.qr_rs = qr_rs; r.qr_hs = qr_hs;
+    return fwd_impl(q, k, v, out, lse, desc_dev, n_blocks, q_rows_total, k_rows_total, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs,
+                    o_rs, o_hs, lse_stride, scale, causal, stream, &r);
 }
 
 // ---------------------------------------------------------------------------
@@ -614,6 +664,25 @@ extern "C" int lv_rope(const void* x, void* out, const void* cos_tab, const void
     int rc = lv_launch_rope(x, out, cos_tab, sin_tab, pos_ids, rows, heads, d, rot, x_row_stride, x_head_stride, o_row_stride,
                             o_head_stride, tab_rows, tab_div, conj, (hipStream_t)stream);
     return rc ? fail(LV_ELAUNCH, "lv_rope: launch failed") : LV_OK;
+}
+
+extern "C" int lv_rope_pack_kv(const void* k, const void* v, void* kv, const void* cos_tab, const void* sin_tab,
+                               const int32_t* pos_ids, int64_t rows, int heads, int d, int rot,
+                               int64_t k_row_stride, int64_t k_head_stride, int64_t v_row_stride, int64_t v_head_stride,
+                               int64_t tab_rows, int tab_div, void* stream) {
+    if (!k || !v || !kv || !cos_tab || !sin_tab) return fail(LV_EINVAL, "lv_rope_pack_kv: null pointer");
+    if (rows < 0 || heads <= 0) return fail(LV_EINVAL, "lv_rope_pack_kv: rows=%lld heads=%d", (long long)rows, heads);
+    if (d <= 0 || d % 8 || rot <= 0 || rot > d || rot % 16)
+        return fail(LV_EINVAL, "lv_rope_pack_kv: d=%d rot=%d (need d %% 8 == 0, rot %% 16 == 0, 0 < rot <= d)", d, rot);
+    if (tab_rows <= 0 || tab_div <= 0) return fail(LV_EINVAL, "lv_rope_pack_kv: tab_rows=%lld tab_div=%d", (long long)tab_rows, tab_div);
+    if (!pos_ids && rows > 0 && (rows - 1) / tab_div >= tab_rows)
+        return fail(LV_EINVAL, "lv_rope_pack_kv: %lld rows / %d need more than the table's %lld rows", (long long)rows, tab_div, (long long)tab_rows);
+    if (k_row_stride % 8 || k_head_stride % 8 || v_row_stride % 8 || v_head_stride % 8 ||
+        ((uintptr_t)k | (uintptr_t)v | (uintptr_t)kv | (uintptr_t)cos_tab | (uintptr_t)sin_tab) % 16)
+        return fail(LV_EINVAL, "lv_rope_pack_kv: rows, heads and tables must be 16-byte aligned");
+    int rc = lv_launch_rope_pack_kv(k, v, kv, cos_tab, sin_tab, pos_ids, rows, heads, d, rot, k_row_stride, k_head_stride,
+                                    v_row_stride, v_head_stride, tab_rows, tab_div, (hipStream_t)stream);
+    return rc ? fail(LV_ELAUNCH, "lv_rope_pack_kv: launch failed") : LV_OK;
 }
 
 // ---------------------------------------------------------------------------

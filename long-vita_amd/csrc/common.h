@@ -42,6 +42,39 @@ __device__ __forceinline__ void pair32(float x, float& a, float& b) {
 __device__ __forceinline__ float pair32_max(float x) { float a, b; pair32(x, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float pair32_sum(float x) { float a, b; pair32(x, a, b); return a + b; }
 
+// ---- bf16 rounding helpers of the rotary embedding (shared by rope.hip and the attention prologue) ----
+// Round to the nearest bf16 (ties to even) and return it as f32.  Done on the bit pattern: written as a
+// float -> __bf16 -> float cast pair the compiler may keep the unrounded value ("excess precision") and
+// fuse the product into the following add, which changes results in the last bit.
+__device__ __forceinline__ float rb(float v) {
+    uint32_t u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+__device__ __forceinline__ __bf16 as_bf16(float rounded) {  // `rounded` already has zero low bits
+    return __builtin_bit_cast(__bf16, (uint16_t)(__float_as_uint(rounded) >> 16));
+}
+// The same rounding by the hardware converter, two values per instruction (round to nearest even is the
+// default mode).  As asm so that the value really passes through bf16 here.
+__device__ __forceinline__ uint32_t rb2(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xFFFF0000u); }
+
+// One rotary pair in the reference's eager bf16 op order (rotary_pos_embedding.py:200-203): x1 / x2 are the
+// elements at column c and c + rot/2, (c1, s1) and (c2, s2) the table values at those columns.  Every product and
+// each sum is rounded to bf16 on its own.  CONJ = the transposed rotation (the gradient).
+template <bool CONJ>
+__device__ __forceinline__ void rope_pair(float a, float b, float c1, float s1, float c2, float s2, float& r1, float& r2) {
+    const uint32_t p1 = CONJ ? rb2(a * c1, b * s2) : rb2(a * c1, b * s1);
+    const uint32_t p2 = CONJ ? rb2(b * c2, a * s1) : rb2(b * c2, a * s2);
+    r1 = CONJ ? lo_f32(p1) + hi_f32(p1) : lo_f32(p1) - hi_f32(p1);
+    r2 = CONJ ? lo_f32(p2) - hi_f32(p2) : lo_f32(p2) + hi_f32(p2);
+}
+
 struct AttnDesc {
     int a_row0;  // fwd: q_row0   bwd: k_row0
     int a_rows;  // fwd: q_rows   bwd: k_rows

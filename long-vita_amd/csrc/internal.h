@@ -13,6 +13,15 @@ struct FwdParams {
     int q_rows_total, k_rows_total;
     int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, o_rs, o_hs, lse_stride;
     float scale, scale_log2e;
+    // rotary embedding applied to the query fragments as they are loaded (null = off): bf16 tables [tab_rows][d],
+    // table row of tensor row i = pos[i] or i / tab_div; q_rot (optional) receives the rotated queries
+    const __bf16* rope_cos;
+    const __bf16* rope_sin;
+    const int32_t* rope_pos;
+    int64_t rope_tab_rows;
+    int rope_tab_div;
+    __bf16* q_rot;
+    int64_t qr_rs, qr_hs;
 };
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
@@ -66,6 +75,9 @@ int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows,
 int lv_launch_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, const int32_t* pos_ids, int64_t rows,
                    int heads, int d, int rot, int64_t x_rs, int64_t x_hs, int64_t o_rs, int64_t o_hs, int64_t tab_rows, int tab_div,
                    int conj, hipStream_t stream);
+int lv_launch_rope_pack_kv(const void* k, const void* v, void* kv, const void* cos_tab, const void* sin_tab, const int32_t* pos_ids,
+                           int64_t rows, int heads, int d, int rot, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                           int64_t tab_rows, int tab_div, hipStream_t stream);
 int lv_launch_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int h, int64_t x_rs,
                         int64_t y_rs, float eps, hipStream_t stream);
 int lv_launch_bias_gelu(const void* x, const void* bias, void* y, int64_t rows, int h, hipStream_t stream);

@@ -532,6 +532,117 @@ def rope(x: torch.Tensor, cos_tab: torch.Tensor, sin_tab: torch.Tensor, pos_ids:
     return _Rope.apply(x, cos_tab, sin_tab, pos_ids, int(tab_div))
 
 
+def _check_rope_tables(cos_tab, sin_tab, pos_ids, rows: int, who: str):
+    _require_gpu(cos_tab, sin_tab)
+    if cos_tab.dtype != torch.bfloat16 or sin_tab.dtype != torch.bfloat16:
+        raise LvAttnError(f"{who}: cos / sin tables must be bfloat16")
+    if cos_tab.shape != sin_tab.shape or cos_tab.dim() != 2 or not cos_tab.is_contiguous() or not sin_tab.is_contiguous():
+        raise LvAttnError(f"{who}: cos / sin tables must be contiguous [tab_rows, rot] of one shape")
+    if pos_ids is not None:
+        _require_gpu(pos_ids)
+        if pos_ids.dtype != torch.int32 or pos_ids.numel() != rows or not pos_ids.is_contiguous():
+            raise LvAttnError(f"{who}: pos_ids must be a contiguous int32 tensor with one entry per row")
+
+
+def attn_fwd_rope_launch(q, k_rot, v, desc: torch.Tensor, scale: float, causal: bool, cos_tab, sin_tab, pos_ids=None,
+                         tab_div: int = 1, out=None, lse=None, q_rot=None):
+    """``attn_fwd_launch`` on UNROTATED queries: the kernel rotates each query row in registers as it loads it (tables
+    and table-row rule of ``rope_launch``, rot == d == 128), so the result equals attn_fwd_launch(rope(q), k_rot, v) bit
+    for bit without the rotated queries ever going through memory.  ``k_rot`` must already be rotated.  ``q_rot``
+    (optional, bf16 [rows, hq, d]) receives the rotated queries (the backward kernels read them)."""
+    q, k_rot, v = _last_contig(q), _last_contig(k_rot), _last_contig(v)
+    _check_qkv(q, k_rot, v)
+    rq, hq, d = q.shape
+    rk, hkv, _ = k_rot.shape
+    _check_rope_tables(cos_tab, sin_tab, pos_ids, rq, "attn_fwd_rope_launch")
+    if d != 128 or cos_tab.shape[1] != d:
+        raise LvAttnError(f"attn_fwd_rope_launch: head dim {d} with rotary width {cos_tab.shape[1]} (the fused rotation needs 128 / 128)")
+    if out is None:
+        out = torch.empty((rq, hq, d), dtype=torch.bfloat16, device=q.device)
+    if lse is None:
+        lse = torch.empty((hq, rq), dtype=torch.float32, device=q.device)
+    if q_rot is not None and (q_rot.shape != q.shape or q_rot.dtype != torch.bfloat16 or q_rot.device != q.device or q_rot.stride(2) != 1):
+        raise LvAttnError("attn_fwd_rope_launch: q_rot must be bf16 of q's shape on q's device with a contiguous last dimension")
+    check(_lib.lib().lvattn_fwd_rope(
+        _ptr(q), _ptr(k_rot), _ptr(v), _ptr(out), _ptr(lse), _ptr(desc), desc.shape[0],
+        rq, rk, hq, hkv, d,
+        q.stride(0), q.stride(1), k_rot.stride(0), k_rot.stride(1), v.stride(0), v.stride(1),
+        out.stride(0), out.stride(1), lse.stride(0), float(scale), int(causal),
+        _ptr(cos_tab), _ptr(sin_tab), _ptr(pos_ids), cos_tab.shape[0], int(tab_div),
+        _ptr(q_rot), q_rot.stride(0) if q_rot is not None else 0, q_rot.stride(1) if q_rot is not None else 0,
+        _stream()), "lvattn_fwd_rope")
+    return out, lse
+
+
+def rope_pack_kv(k: torch.Tensor, v: torch.Tensor, cos_tab: torch.Tensor, sin_tab: torch.Tensor, pos_ids=None, tab_div: int = 1,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """k, v [rows, heads, d] bf16 -> kv [2, rows, heads, d] contiguous with kv[0] = rope(k), kv[1] = v, in one pass
+    (the K/V message of a ring step, rotated on the way in)."""
+    k, v = _last_contig(k), _last_contig(v)
+    _require_gpu(k, v)
+    if k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16 or k.dim() != 3 or k.shape != v.shape:
+        raise LvAttnError("rope_pack_kv expects k, v bf16 [rows, heads, d] of one shape")
+    rows, heads, d = k.shape
+    _check_rope_tables(cos_tab, sin_tab, pos_ids, rows, "rope_pack_kv")
+    if out is None:
+        out = torch.empty((2, rows, heads, d), dtype=torch.bfloat16, device=k.device)
+    elif out.shape != (2, rows, heads, d) or out.dtype != torch.bfloat16 or out.device != k.device or not out.is_contiguous():
+        raise LvAttnError("rope_pack_kv: out must be contiguous bf16 [2, rows, heads, d] on k's device")
+    check(_lib.lib().lv_rope_pack_kv(_ptr(k), _ptr(v), _ptr(out), _ptr(cos_tab), _ptr(sin_tab), _ptr(pos_ids), rows, heads, d,
+                                     cos_tab.shape[1], k.stride(0), k.stride(1), v.stride(0), v.stride(1), cos_tab.shape[0],
+                                     int(tab_div), _stream()), "lv_rope_pack_kv")
+    return out
+
+
+class _RopeVarlenAttention(torch.autograd.Function):
+    """Rotary embedding of q and k + packed attention as one differentiable op.  Forward: K is rotated by the
+    bandwidth-bound kernel (every query block reads it), Q inside the attention kernel, which also writes the rotated
+    queries out when a backward pass will need them.  Backward: the attention backward on the rotated q / k, then the
+    transposed rotation of dq and dk in place."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cos_tab, sin_tab, pos_ids, tab_div, cu_seqlens, scale, causal):
+        desc = blocks_on_device(cu_seqlens, causal, False, q.device)
+        total = q.shape[0]
+        covered = len(cu_seqlens) > 1 and cu_seqlens[0] == 0 and cu_seqlens[-1] == total
+        out = None if covered else torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+        lse = None if covered else torch.full((q.shape[1], total), float("-inf"), dtype=torch.float32, device=q.device)
+        need_bwd = any(ctx.needs_input_grad[:3])
+        k_rot = rope_launch(k, cos_tab, sin_tab, pos_ids, tab_div)
+        # rows outside every segment are not visited by the kernel: their q_rot is never read either
+        q_rot = torch.empty(q.shape, dtype=q.dtype, device=q.device) if need_bwd else None
+        out, lse = attn_fwd_rope_launch(q, k_rot, v, desc, scale, causal, cos_tab, sin_tab, pos_ids, tab_div, out, lse, q_rot)
+        if need_bwd:
+            ctx.save_for_backward(q_rot, k_rot, v, out, lse, cos_tab, sin_tab, pos_ids if pos_ids is not None else torch.empty(0))
+        ctx.has_pos = pos_ids is not None
+        ctx.tab_div, ctx.cu_seqlens, ctx.scale, ctx.causal = tab_div, tuple(cu_seqlens), scale, causal
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        q_rot, k_rot, v, out, lse, cos_tab, sin_tab, pos = ctx.saved_tensors
+        pos = pos if ctx.has_pos else None
+        desc_q = blocks_on_device(ctx.cu_seqlens, ctx.causal, False, q_rot.device)
+        desc_k = blocks_on_device(ctx.cu_seqlens, ctx.causal, True, q_rot.device)
+        dq, dk, dv, _ = attn_bwd_launch(q_rot, k_rot, v, out, dout, lse, desc_q, desc_k, ctx.scale, ctx.causal)
+        rope_launch(dq, cos_tab, sin_tab, pos, ctx.tab_div, conj=True, out=dq)
+        rope_launch(dk, cos_tab, sin_tab, pos, ctx.tab_div, conj=True, out=dk)
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def rope_varlen_attention(q, k, v, cos_tab, sin_tab, cu_seqlens: Sequence[int], scale: float | None = None, causal: bool = True,
+                          pos_ids: torch.Tensor | None = None, tab_div: int = 1):
+    """varlen_attention(rope(q), rope(k), v) with the query rotation folded into the attention kernel (head dim 128,
+    rotary width 128).  q [T,Hq,128], k/v [T,Hkv,128] bf16 UNROTATED; cos_tab / sin_tab [tab_rows, 128] bf16; table row
+    of token t = pos_ids[t] (int32) or t // tab_div.  Returns (out, lse); differentiable in q, k, v, and every result
+    (out, lse, dq, dk, dv) is bit-identical to the unfused sequence rope -> varlen_attention."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    return _RopeVarlenAttention.apply(q, k, v, cos_tab, sin_tab, pos_ids, int(tab_div), tuple(int(x) for x in cu_seqlens),
+                                      float(scale), bool(causal))
+
+
 # ---------------------------------------------------------------------------
 # InternViT encoder pieces around the GEMMs
 # ---------------------------------------------------------------------------

@@ -38,13 +38,27 @@ class HipBackend:
         from . import ops
         self.ops = ops
 
-    def block_fwd(self, q3, k3, v3, qr, kr, causal, shift, scale, out_blk, lse_blk):
+    def block_fwd(self, q3, k3, v3, qr, kr, causal, shift, scale, out_blk, lse_blk, rope=None):
         desc = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, False, q3.device)
-        self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, causal, out_blk, lse_blk)
+        if rope is not None:    # unrotated queries, rotated in the kernel's prologue
+            self.ops.attn_fwd_rope_launch(q3, k3, v3, desc, scale, causal, rope[0], rope[1], out=out_blk, lse=lse_blk)
+        else:
+            self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, causal, out_blk, lse_blk)
 
-    def block_fwd_rects(self, q3, k3, v3, rects, scale, out_blk, lse_blk):
+    def block_fwd_rects(self, q3, k3, v3, rects, scale, out_blk, lse_blk, rope=None):
         desc = self.ops.rects_blocks_on_device(rects, False, q3.device)
-        self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, True, out_blk, lse_blk)
+        if rope is not None:
+            self.ops.attn_fwd_rope_launch(q3, k3, v3, desc, scale, True, rope[0], rope[1], out=out_blk, lse=lse_blk)
+        else:
+            self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, True, out_blk, lse_blk)
+
+    def pack_kv(self, k3, v3, kv, rope=None):
+        """kv [2, s, Hkv, d] := (k3, v3), the key half rotated on the way when ``rope`` = (cos, sin) tables is given."""
+        if rope is not None:
+            self.ops.rope_pack_kv(k3, v3, rope[0], rope[1], out=kv)
+        else:
+            kv[0].copy_(k3)
+            kv[1].copy_(v3)
 
     def block_bwd_rects(self, q3, k3, v3, out3, dout3, lse, delta, rects, scale, dq_acc, dk_acc, dv_acc):
         desc_q = self.ops.rects_blocks_on_device(rects, False, q3.device)
@@ -197,12 +211,13 @@ class RingAttention:
                 pairs.append(rects)
         return pairs
 
-    def _fwd_rects(self, be, q3, k3, v3, rects, scale, out_blk, lse_blk):
+    def _fwd_rects(self, be, q3, k3, v3, rects, scale, out_blk, lse_blk, rope=None):
+        kw = {} if rope is None else {"rope": rope}
         if hasattr(be, "block_fwd_rects"):
-            be.block_fwd_rects(q3, k3, v3, rects, scale, out_blk, lse_blk)
+            be.block_fwd_rects(q3, k3, v3, rects, scale, out_blk, lse_blk, **kw)
         else:
             for q0, ql, k0, kl, sh in rects:
-                be.block_fwd(q3, k3, v3, (q0, ql), (k0, kl), True, sh, scale, out_blk, lse_blk)
+                be.block_fwd(q3, k3, v3, (q0, ql), (k0, kl), True, sh, scale, out_blk, lse_blk, **kw)
 
     def _bwd_rects(self, be, q3, k3, v3, out3, dout3, lse, delta, rects, scale, dq_acc, dk_acc, dv_acc):
         if hasattr(be, "block_bwd_rects"):
@@ -212,9 +227,12 @@ class RingAttention:
                 be.block_bwd(q3, k3, v3, out3, dout3, lse, delta, (q0, ql), (k0, kl), True, sh, scale, dq_acc, dk_acc, dv_acc)
 
     # -- forward -----------------------------------------------------------
-    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False, cu_seqlens=None):
+    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False, cu_seqlens=None, rope=None):
         """q [s, b, Hq*d], k/v [s, b, Hkv*d] (local zig-zag shard) -> out [s, b, Hq*d].  With ``cu_seqlens`` (global
-        segment boundaries, b == 1) attention stays inside the packed segments."""
+        segment boundaries, b == 1) attention stays inside the packed segments.  With ``rope`` = (cos, sin), bf16 tables
+        [s, d] for THIS rank's rows (the zig-zag slice of the table, rotary_pos_embedding.py:36-47; b == 1), q and k come
+        UNROTATED: the keys are rotated while they are packed into the ring message, the queries inside the block
+        kernels (forward only: the prefill path)."""
         be = self._be()
         s_loc, b, hq_d = q.shape
         d = hq_d // n_heads
@@ -235,8 +253,16 @@ class RingAttention:
         w = self._buffers(("fwd", s_loc, b, n_heads, hkv, d, q.dtype, str(dev)), make)
         kv, out_acc, out_blk, lse_blk = w["kv"], w["out_acc"], w["out_blk"], w["lse_blk"]
         # K and V of this rank as ONE message [2, s, Hkv, d]
-        kv[0][0].copy_(k.reshape(s_loc, b * hkv, d))
-        kv[0][1].copy_(v.reshape(s_loc, b * hkv, d))
+        if rope is not None:
+            if b != 1:
+                raise ValueError("the fused rotary embedding on the ring needs micro-batch 1")
+            be.pack_kv(k.reshape(s_loc, hkv, d), v.reshape(s_loc, hkv, d), kv[0], rope)
+        elif hasattr(be, "pack_kv"):
+            be.pack_kv(k.reshape(s_loc, b * hkv, d), v.reshape(s_loc, b * hkv, d), kv[0])
+        else:
+            kv[0][0].copy_(k.reshape(s_loc, b * hkv, d))
+            kv[0][1].copy_(v.reshape(s_loc, b * hkv, d))
+        rkw = {} if rope is None else {"rope": rope}
         lse_acc = torch.empty((b * n_heads, s_loc), dtype=torch.float32, device=dev)   # returned (saved for backward)
         packed = cu_seqlens is not None
         if packed:      # rows are first touched by different chunk pairs: start from the neutral element
@@ -254,13 +280,13 @@ class RingAttention:
                 t0 = torch.cuda.Event(enable_timing=True); t0.record()
             if not packed:
                 qr, kr, causal, shift = self.step_rect(step, s_loc)
-                be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk)
+                be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk, **rkw)
                 # step 0 covers every local row: it initialises the running result instead of merging into it
                 be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1], init=(step == 0))
             else:
                 for rects in self.segment_rects(step, s_loc, cu_seqlens):
                     if rects:
-                        self._fwd_rects(be, q3, cur[0], cur[1], rects, scale, out_blk, lse_blk)
+                        self._fwd_rects(be, q3, cur[0], cur[1], rects, scale, out_blk, lse_blk, rope)
                         lo = min(r[0] for r in rects)
                         hi = max(r[0] + r[1] for r in rects)
                         be.merge(out_acc, lse_acc, out_blk, lse_blk, lo, hi - lo)

@@ -136,3 +136,25 @@ def apply_rotary_pos_emb(t: torch.Tensor, freqs: torch.Tensor, config, cu_seqlen
     if cu_seqlens is None:
         return apply_rotary_pos_emb_bshd(t, freqs, rotary_interleaved=interleaved)
     return apply_rotary_pos_emb_thd(t, cu_seqlens, freqs, rotary_interleaved=interleaved)
+
+
+def rope_flash_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, freqs: torch.Tensor,
+                         actual_seq_len=None, scale: float | None = None) -> torch.Tensor:
+    """apply_rotary_pos_emb on query and key followed by causal flash attention, as ONE op (what
+    --use-fused-rotary-pos-emb + --use-flash-attn amount to between Megatron's SelfAttention QKV projection and its
+    output projection): query [s, 1, Hq, 128], key / value [s, 1, Hkv, 128] UNROTATED, freqs [s, 1, 1, 128] fp32 angles
+    (already gathered by position ids / sliced for the CP rank as RotaryEmbedding.forward leaves them, :114-121) ->
+    [s, 1, Hq*128].  ``actual_seq_len`` = cumulative END offsets of packed segments (None: one causal segment).
+    The keys are rotated by the bandwidth-bound kernel, the queries inside the attention kernel; results and gradients
+    are bit-identical to apply_rotary_pos_emb + flash_attention_forward on this package's kernels."""
+    _check(query, False)
+    s, b, hq, d = query.shape
+    if b != 1:
+        raise ops.LvAttnError("rope_flash_attention needs micro-batch 1 (as every shipped script uses)")
+    if freqs.shape[0] < s or freqs.shape[-1] != d:
+        raise ops.LvAttnError(f"freqs {tuple(freqs.shape)} does not cover [{s}, .., {d}]")
+    cos_t, sin_t = _tables(freqs)
+    cu = [0, s] if actual_seq_len is None else [0] + [int(x) for x in actual_seq_len]
+    out, _ = ops.rope_varlen_attention(query.reshape(s, hq, d), key.reshape(s, -1, d), value.reshape(s, -1, d), cos_t, sin_t, cu,
+                                       scale, True)
+    return out.reshape(s, 1, hq * d)

@@ -260,3 +260,41 @@ def test_ring_hip_backend_packed_segments(cp, cu):
     for idx, ref, H in ((2, rdq, Hq), (3, rdk, Hkv), (4, rdv, Hkv)):
         got = unzigzag([r[idx] for r in res], cp).reshape(S, H, D)
         assert rel(got, ref) <= REL_TOL, idx
+
+
+@pytest.mark.parametrize("cp,cu", [(2, None), (4, None), (4, [0, 700, 2100, 2101, 3900, 4096])])
+def test_ring_forward_with_rotary_embedding_folded_in(cp, cu):
+    """Ring forward on UNROTATED q / k with the rotary tables of each rank's rows (keys rotated while they are packed
+    into the ring message, queries inside the block kernels) equals, bit for bit, the ring forward on q / k rotated
+    beforehand by the standalone kernel."""
+    from long_vita_amd import ops
+    from long_vita_amd.ring_context_parallel import RingAttention
+    from oracle import rope_ref as R
+    S = 4096 if cu else 1024 * cp
+    Hq, Hkv, D = 10, 2, 128
+    g = torch.Generator().manual_seed(7 + cp)
+    q = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    ang = torch.from_numpy(R.angle_table(S, D, 1000000)).reshape(S, D)
+    cos_all, sin_all = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    fabric = LoopbackFabric(cp)
+    dev = torch.device("cuda", 0)
+    kw = {"cu_seqlens": tuple(cu)} if cu else {}
+
+    def body(r):
+        torch.cuda.set_device(0)
+        ql, kl, vl = (zigzag_local(x, cp, r).to(dev) for x in (q, k, v))
+        cos_l, sin_l = zigzag_local(cos_all, cp, r).contiguous().to(dev), zigzag_local(sin_all, cp, r).contiguous().to(dev)
+        s_loc = S // cp
+        eng = RingAttention(None, cp, r, causal=True, comm=LoopbackComm(fabric, r))
+        fused, lse_f = eng.forward(ql.reshape(s_loc, 1, -1), kl.reshape(s_loc, 1, -1), vl.reshape(s_loc, 1, -1), Hq, scale,
+                                   return_state=True, rope=(cos_l, sin_l), **kw)
+        fused, lse_f = fused.clone(), lse_f.clone()
+        qr, kr = ops.rope_launch(ql, cos_l, sin_l), ops.rope_launch(kl, cos_l, sin_l)
+        plain, lse_p = eng.forward(qr.reshape(s_loc, 1, -1), kr.reshape(s_loc, 1, -1), vl.reshape(s_loc, 1, -1), Hq, scale,
+                                   return_state=True, **kw)
+        torch.cuda.synchronize()
+        return torch.equal(fused, plain) and torch.equal(lse_f, lse_p)
+    assert all(run_virtual_ranks(cp, body))

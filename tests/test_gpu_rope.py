@@ -121,3 +121,113 @@ def test_rope_argument_errors():
     with pytest.raises(_lib.LvAttnError):    # rotary width not a multiple of 16
         ops.rope_launch(x, tab[:, :24].contiguous(), tab[:, :24].contiguous(), None, 2)
     ops.rope_launch(x, tab, tab, None, 2)     # 8 rows / 2 = 4 table rows: fine
+
+
+def _qwen_case(S, seed, HQ=10, HKV=2, D=128):
+    rs = np.random.RandomState(seed)
+    freqs = R.angle_table(S, D, 1000000)
+    cos_t, sin_t = _tables(freqs)
+    qkv = torch.from_numpy((0.7 * rs.randn(S, (HQ + 2 * HKV) * D)).astype(np.float32)).to(torch.bfloat16).cuda()
+    q = qkv[:, : HQ * D].view(S, HQ, D)                       # strided views of one fused projection output
+    k = qkv[:, HQ * D:(HQ + HKV) * D].view(S, HKV, D)
+    v = qkv[:, (HQ + HKV) * D:].view(S, HKV, D)
+    do = torch.from_numpy(rs.randn(S, HQ, D).astype(np.float32)).to(torch.bfloat16).cuda()
+    return freqs, cos_t, sin_t, q, k, v, do
+
+
+@pytest.mark.parametrize("cu", [[0, 777], [0, 258, 1290, 1291, 3000], [0, 513, 1024]])
+def test_rotation_inside_the_attention_kernel_equals_the_two_pass_path(cu):
+    """The query rotation folded into the attention kernel (lvattn_fwd_rope) + the standalone K rotation against the
+    two-pass path (lv_rope on q and k, then lvattn_fwd / lvattn_bwd): out, lse, the rotated queries the kernel writes
+    out, and dq / dk / dv must be IDENTICAL bit for bit; and within the attention tolerance of the float64 oracle on the
+    oracle-rotated inputs."""
+    from long_vita_amd import ops
+    from oracle import attention_ref as A
+    S = cu[-1]
+    freqs, cos_t, sin_t, q, k, v, do = _qwen_case(S, 11 + len(cu))
+    scale = 1.0 / np.sqrt(128.0)
+    # two-pass reference path on this package's kernels
+    q2 = ops.rope(q.detach().clone().requires_grad_(True), cos_t, sin_t)
+    qa = q.detach().clone().requires_grad_(True)
+    ka = k.detach().clone().requires_grad_(True)
+    va = v.detach().clone().requires_grad_(True)
+    q_rot, k_rot = ops.rope(qa, cos_t, sin_t), ops.rope(ka, cos_t, sin_t)
+    out_a, lse_a = ops.varlen_attention(q_rot, k_rot, va, cu, scale, True)
+    out_a.backward(do)
+    # fused
+    qb = q.detach().clone().requires_grad_(True)
+    kb = k.detach().clone().requires_grad_(True)
+    vb = v.detach().clone().requires_grad_(True)
+    out_b, lse_b = ops.rope_varlen_attention(qb, kb, vb, cos_t, sin_t, cu, scale, True)
+    out_b.backward(do)
+    assert torch.equal(out_a, out_b) and torch.equal(lse_a, lse_b)
+    for a, b, name in ((qa.grad, qb.grad, "dq"), (ka.grad, kb.grad, "dk"), (va.grad, vb.grad, "dv")):
+        assert torch.equal(a, b), name
+    # the side output of the kernel: the rotated queries
+    desc = ops.blocks_on_device(cu, True, False, q.device)
+    side = torch.zeros_like(q2)
+    ops.attn_fwd_rope_launch(q, k_rot.detach(), v, desc, scale, True, cos_t, sin_t, q_rot=side)
+    assert torch.equal(side, q2.detach())
+    # oracle: rotate with the oracle, attend in float64
+    want_q = R.apply_bshd(q.float().cpu().numpy()[:, None], freqs)[:, 0]
+    want_k = R.apply_bshd(k.float().cpu().numpy()[:, None], freqs)[:, 0]
+    ref_o, ref_lse = A.varlen_attention(torch.from_numpy(want_q), torch.from_numpy(want_k), v.float().cpu(), cu, scale)
+    err = np.abs(out_b.detach().float().cpu().numpy() - ref_o).max() / np.abs(ref_o).max()
+    assert err <= 2e-2, err
+    assert np.abs(lse_b.cpu().numpy() - ref_lse).max() <= 1e-3
+
+
+def test_rope_pack_kv_and_packed_positions(golden_dir):
+    """kv[0] = rope(k) bit-exact against the reference-made fixture (packed position ids), kv[1] = v, from strided
+    inputs in one pass."""
+    from long_vita_amd import ops
+    g = _g(golden_dir)
+    cos_t, sin_t = _tables(g["thd.freqs"])
+    pos = torch.from_numpy(R.thd_position_ids(g["thd.cu"]).astype(np.int32)).cuda()
+    t = _bf(g["thd.t"])
+    T, H, D = t.shape
+    both = torch.zeros(T, 2 * H * D + 16, dtype=torch.bfloat16, device="cuda")
+    kview = both[:, :H * D].view(T, H, D)
+    vview = both[:, H * D + 16:].view(T, H, D)
+    kview.copy_(t)
+    vview.copy_(torch.flip(t, dims=(0,)))
+    kv = ops.rope_pack_kv(kview, vview, cos_t, sin_t, pos, 1)
+    assert np.array_equal(kv[0].float().cpu().numpy(), g["thd.out"])
+    assert torch.equal(kv[1], vview)
+    # position = row index, Qwen shape
+    freqs, cos_t, sin_t, q, k, v, _ = _qwen_case(515, 3)
+    kv = ops.rope_pack_kv(k, v, cos_t, sin_t)
+    assert torch.equal(kv[0], ops.rope_launch(k, cos_t, sin_t)) and torch.equal(kv[1], v)
+
+
+def test_fused_rope_argument_errors():
+    from long_vita_amd import _lib, ops
+    q = torch.zeros(64, 2, 64, device="cuda", dtype=torch.bfloat16)
+    tab = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    desc = ops.blocks_on_device([0, 64], True, False, q.device)
+    with pytest.raises(_lib.LvAttnError):        # head dim 64: the fused rotation is built for 128
+        ops.attn_fwd_rope_launch(q, q, q, desc, 0.125, True, tab, tab)
+    q = torch.zeros(64, 2, 128, device="cuda", dtype=torch.bfloat16)
+    tab = torch.zeros(32, 128, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(_lib.LvAttnError):        # 64 rows, table of 32
+        ops.attn_fwd_rope_launch(q, q, q, desc, 0.09, True, tab, tab)
+    with pytest.raises(_lib.LvAttnError):
+        ops.rope_pack_kv(q, q, tab, tab)
+
+
+def test_rope_flash_attention_entry(golden_dir):
+    """The Megatron-shaped entry ([s, 1, h, d] tensors, fp32 angle tensor) equals apply_rotary_pos_emb followed by the
+    packed attention, bit for bit."""
+    from types import SimpleNamespace
+    from long_vita_amd import ops
+    from long_vita_amd.rotary_pos_embedding import apply_rotary_pos_emb, rope_flash_attention
+    S, HQ, HKV, D = 600, 10, 2, 128
+    freqs_np, _, _, q, k, v, _ = _qwen_case(S, 21)
+    freqs = torch.from_numpy(freqs_np).cuda()
+    cfg = SimpleNamespace(rotary_interleaved=False)
+    ends = [100, 356, 600]
+    qr = apply_rotary_pos_emb(q.contiguous().view(S, 1, HQ, D), freqs, cfg)
+    kr = apply_rotary_pos_emb(k.contiguous().view(S, 1, HKV, D), freqs, cfg)
+    want, _ = ops.varlen_attention(qr.view(S, HQ, D), kr.view(S, HKV, D), v, [0] + ends, 1.0 / np.sqrt(D), True)
+    got = rope_flash_attention(q.view(S, 1, HQ, D), k.view(S, 1, HKV, D), v.view(S, 1, HKV, D), freqs, ends)
+    assert got.shape == (S, 1, HQ * D) and torch.equal(got.view(S, HQ, D), want)
