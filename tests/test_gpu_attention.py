@@ -321,3 +321,52 @@ def test_every_backward_kernel_variant(dq, dkdv):
             assert rel_err(qc.grad, rdq) <= REL_TOL and rel_err(kc.grad, rdk) <= REL_TOL and rel_err(vc.grad, rdv) <= REL_TOL, (dq, dkdv, cu)
     finally:
         _lib.check(_lib.lib().lvattn_select_bwd_kernels(b"default", b"default"), "select")
+
+
+def test_full_size_backward_invariants_cfg3_packed():
+    """cfg3-B at full size: 131,072 tokens packed into segments with log-uniform lengths in [256, 32768] (seed 1234, the
+    benchmark's packing), 40 / 8 heads, forward + backward.  The two size-independent identities of the single-segment
+    test hold PER SEGMENT (attention never crosses a boundary): sum_j dV[j] over a segment's keys = sum of dO over the
+    segment's rows and the group's heads;  sum_i <q_i, dq_i> = sum_j <k_j, dk_j> over the segment.  A sample of rows is
+    also checked against the float64 oracle on its own segment."""
+    import math
+    from long_vita_amd import ops
+    S, Hq, Hkv, D = 131072, 40, 8, 128
+    rs = np.random.RandomState(1234)
+    lens = []
+    while sum(lens) < S:
+        lens.append(int(math.exp(rs.uniform(math.log(256), math.log(32768)))))
+    cu = [0]
+    for L in lens:
+        cu.append(min(S, cu[-1] + L))
+    cu[-1] = S
+    assert len(cu) > 5
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(4)
+    rnd = lambda *shape: (torch.randn(*shape, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    q, k, v, do = rnd(S, Hq, D).requires_grad_(True), rnd(S, Hkv, D).requires_grad_(True), rnd(S, Hkv, D).requires_grad_(True), rnd(S, Hq, D)
+    scale = A.default_scale(D)
+    out, lse = ops.varlen_attention(q, k, v, cu, scale, True)
+    out.backward(do)
+    torch.cuda.synchronize()
+    rep = Hq // Hkv
+    for a, b in zip(cu[:-1], cu[1:]):
+        dv_sum = v.grad[a:b].double().sum(0)
+        do_sum = do[a:b].double().sum(0).reshape(Hkv, rep, D).sum(1)
+        assert (dv_sum - do_sum).abs().max().item() <= 1e-2 * max(do_sum.abs().max().item(), 1.0), (a, b)
+        qdq = (q.detach()[a:b].double() * q.grad[a:b].double()).sum((0, 2)).reshape(Hkv, rep).sum(1)
+        kdk = (k.detach()[a:b].double() * k.grad[a:b].double()).sum((0, 2))
+        assert (qdq - kdk).abs().max().item() <= 2e-2 * max(qdq.abs().max().item(), kdk.abs().max().item(), 1.0), (a, b)
+    # rows of the forward against the oracle: first, a middle and the last row of three segments
+    for si in (0, len(cu) // 2, len(cu) - 2):
+        a, b = cu[si], cu[si + 1]
+        for row in (a, (a + b) // 2, b - 1):
+            n = row - a + 1
+            for h in (0, 17, 39):
+                kk = k.detach()[a:row + 1, h // rep].double()
+                s_ = (kk @ q.detach()[row, h].double()) * scale
+                p = torch.softmax(s_, 0)
+                want = p @ v.detach()[a:row + 1, h // rep].double()
+                got = out.detach()[row, h].double()
+                assert (got - want).abs().max().item() <= REL_TOL * max(want.abs().max().item(), 1e-2), (row, h, n)
+                assert abs(lse[h, row].item() - torch.logsumexp(s_, 0).item()) <= LSE_TOL

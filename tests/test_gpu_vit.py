@@ -338,3 +338,27 @@ def test_image_encode_dealt_over_cp_ranks_two_processes_real_model():
     import os
     import torch.multiprocessing as mp
     mp.spawn(_vision_cp_worker, args=(2, 37500 + (os.getpid() % 2000)), nprocs=2, join=True)
+
+
+def test_full_size_tower_64_frames_24_layers():
+    """BASELINE configs[1] at full size: InternViT-300M (24 layers, 16 heads x 64, 1025 tokens) on 64 frames of
+    448 x 448 -> pixel shuffle -> projector.  Frames are independent, so every frame of the batched run must equal the
+    same frame run alone (GEMM tilings may differ with the batch: a small tolerance), and the outputs are finite."""
+    from long_vita_amd import intern_vit as iv, vision_model as vmod
+    torch.manual_seed(2)
+    cfg = iv.InternViTConfig()
+    assert cfg.num_layers == 24 and cfg.hidden_size == 1024 and cfg.num_attention_heads == 16
+    m = vmod.MegatronVisionModel(hidden_size=5120, vit_config=cfg, vision_projector_freeze=True).to(torch.bfloat16).cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = (torch.randn(64, 3, cfg.img_h, cfg.img_w, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    with torch.no_grad():
+        feats = m(images=img)
+        assert feats.shape == (64, 256, 5120) and torch.isfinite(feats.float()).all()
+        for i in (0, 31, 63):
+            alone = m(images=img[i:i + 1])
+            scale = alone.float().abs().max().item()
+            err = (feats[i:i + 1].float() - alone.float()).abs().max().item()
+            assert err <= 3e-2 * scale, (i, err, scale)
+        # the tower alone: [64, 1025, 1024]
+        tower = m.vit(img)
+        assert tower.shape == (64, 1025, 1024) and torch.isfinite(tower.float()).all()
