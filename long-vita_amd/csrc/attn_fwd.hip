@@ -47,11 +47,22 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
 
     // block id -> (kv head, descriptor, head within group); heads of a group are adjacent
     // so that the workgroups in flight stream the same K/V tiles.
-    const int bid = blockIdx.x;
-    const int hg = bid % p.group;
-    const int rest = bid / p.group;
-    const int blk = rest % p.n_blocks;
-    const int kvh = rest / p.n_blocks;
+    int hg, blk, kvh;
+    if (p.head_per_xcd) {   // all work items of a KV head on one XCD, back to back (see lv_head_per_xcd)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int per = p.n_blocks * p.group;
+        kvh = (slot / per) * 8 + xcd;
+        if (kvh >= p.hkv) return;
+        const int rem = slot % per;
+        blk = rem / p.group;
+        hg = rem % p.group;
+    } else {
+        const int bid = blockIdx.x;
+        hg = bid % p.group;
+        const int rest = bid / p.group;
+        blk = rest % p.n_blocks;
+        kvh = rest / p.n_blocks;
+    }
     const int head = kvh * p.group + hg;
 
     const AttnDesc dsc = p.desc[blk];
@@ -266,8 +277,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
 }
 
 template <int D, int NW>
-static void launch_fwd_d(const FwdParams& p, int causal, hipStream_t stream) {
-    dim3 grid((unsigned)((int64_t)p.n_blocks * p.hq)), block(NW * 64);
+static void launch_fwd_d(const FwdParams& p0, int causal, hipStream_t stream) {
+    FwdParams p = p0;
+    p.head_per_xcd = lv_head_per_xcd(p) ? 1 : 0;
+    dim3 grid(p.head_per_xcd ? (unsigned)(((p.hkv + 7) / 8) * 8 * p.n_blocks * p.group) : (unsigned)((int64_t)p.n_blocks * p.hq)), block(NW * 64);
     size_t lds = 4 * 64 * D * 2;
     if (causal) hipLaunchKernelGGL((lv_fwd_kernel<D, true, NW>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((lv_fwd_kernel<D, false, NW>), grid, block, lds, stream, p);

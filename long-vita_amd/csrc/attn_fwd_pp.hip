@@ -83,14 +83,24 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
     // unit take consecutive slots of ONE XCD, so they stream the same K / V tiles through the same L2 side by side;
     // units go round the XCDs in heaviest-first order.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int hg = slot % p.group;
-    const int unit = (slot / p.group) * 8 + xcd;
-    if (unit >= p.n_blocks * p.hkv) return;
+    int hg, blk, kvh;
+    if (p.head_per_xcd) {   // all work items of a KV head on one XCD, back to back (see lv_head_per_xcd)
+        const int per = p.n_blocks * p.group;
+        kvh = (slot / per) * 8 + xcd;
+        if (kvh >= p.hkv) return;
+        const int rem = slot % per;
+        blk = rem / p.group;
+        hg = rem % p.group;
+    } else {
+        hg = slot % p.group;
+        const int unit = (slot / p.group) * 8 + xcd;
+        if (unit >= p.n_blocks * p.hkv) return;
 #if LV_PP_MAP == 1
-    const int blk = unit / p.hkv, kvh = unit % p.hkv;      // with 8 KV heads: one KV head per XCD
+        blk = unit / p.hkv, kvh = unit % p.hkv;      // with 8 KV heads: one KV head per XCD
 #else
-    const int blk = unit % p.n_blocks, kvh = unit / p.n_blocks;
+        blk = unit % p.n_blocks, kvh = unit / p.n_blocks;
 #endif
+    }
 #endif
     const int head = kvh * p.group + hg;
 
@@ -392,11 +402,14 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 }
 
 template <int D>
-static void launch_pp(const FwdParams& p, int causal, hipStream_t stream) {
+static void launch_pp(const FwdParams& p0, int causal, hipStream_t stream) {
+    FwdParams p = p0;
 #if LV_PP_MAP == 0
     dim3 grid((unsigned)((int64_t)p.n_blocks * p.hq)), block(512);
 #else
-    dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(512);
+    p.head_per_xcd = lv_head_per_xcd(p) ? 1 : 0;
+    dim3 grid(p.head_per_xcd ? (unsigned)(((p.hkv + 7) / 8) * 8 * p.n_blocks * p.group)
+                             : (unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(512);
 #endif
     size_t lds = (size_t)3 * 2 * 64 * D * 2;  // 3 slots x (K tile + V tile)
     if constexpr (D == 128) {

@@ -13,6 +13,7 @@ struct FwdParams {
     int q_rows_total, k_rows_total;
     int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, o_rs, o_hs, lse_stride;
     float scale, scale_log2e;
+    int head_per_xcd;   // workgroup order: every work item of a KV head on ONE XCD, back to back (set by the launchers)
     // rotary embedding applied to the query fragments as they are loaded (null = off): bf16 tables [tab_rows][d],
     // table row of tensor row i = pos[i] or i / tab_div; q_rot (optional) receives the rotated queries
     const __bf16* rope_cos;
@@ -23,6 +24,11 @@ struct FwdParams {
     __bf16* q_rot;
     int64_t qr_rs, qr_hs;
 };
+// Workgroup i of a launch runs on XCD i % 8, and every XCD has its own L2.  When ALL the work items of one KV head
+// (query blocks x the group's query heads) fit on an XCD's 32 CUs at once, they are given consecutive slots of one XCD:
+// the head's K / V then come into that L2 once instead of once per XCD that hosts one of its items (the vision
+// tower: 1024 heads x 4-5 query blocks, where the plain order fetched K / V four times, L2 hit rate 41 %).
+inline bool lv_head_per_xcd(const FwdParams& p) { return (int64_t)p.n_blocks * p.group <= 32 && p.hkv >= 8; }
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
 int lv_launch_fwd_pp16(const FwdParams& p, int causal, hipStream_t stream);      // ping-pong form on 16x16x32 MFMAs, d = 128
