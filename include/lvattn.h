@@ -264,6 +264,9 @@ int lv_rope_pack_kv(const void* k, const void* v, void* kv, const void* cos_tab,
  *   dgamma_dbeta [2, h] fp32 (dgamma then dbeta), summed over rows in a fixed order through `workspace`
  *   (lv_layernorm_bwd_workspace_bytes(rows, h) bytes of device memory, contents undefined afterwards).
  * lv_bias_scale_residual: `residual + (out + bias) * ls` (:59-63, :74-77); bias may be NULL.
+ * lv_bias_scale_residual_layernorm: the same followed by the NEXT sub-block's LayerNorm (:69 after :59-66; the next
+ *   layer's :48 after :74-77) in one pass: out = residual + (x + bias) * ls, normed = LayerNorm(out); bit-identical to
+ *   the two calls, one read of `out` less.
  * lv_patchify: the patch side of conv1 (:139-145, :203-205) as a GEMM operand: [n, c, H, W] ->
  *   [n*(H/p)*(W/p), kpad], column (ch*p + ky)*p + kx (= conv1.weight.view(out, -1)), zero-padded to kpad.
  * lv_embed_tokens: class-token concat, conv bias, position embedding and the [b,s,h] -> [s,b,h] permute
@@ -278,6 +281,9 @@ int lv_layernorm_bwd(const void* x, const void* dy, const void* gamma, void* dx,
                      int64_t dx_row_stride, float eps, void* stream);
 int lv_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* residual, void* out,
                            int64_t rows, int h, void* stream);
+int lv_bias_scale_residual_layernorm(const void* x, const void* bias, const void* ls, const void* residual, void* out,
+                                     void* normed, const void* gamma, const void* beta, int64_t rows, int h, float eps,
+                                     void* stream);
 int lv_patchify(const void* img, void* patches, int n, int c, int height, int width, int patch, int kpad, void* stream);
 int lv_embed_tokens(const void* proj, const void* conv_bias, const void* class_token, const void* pos_emb, void* tokens,
                     int n, int n_patches, int n_class, int h, void* stream);

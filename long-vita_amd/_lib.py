@@ -56,6 +56,7 @@ _SIGNATURES = {
     "lv_layernorm_bwd_workspace_bytes": (_i64, [_i64, _int]),
     "lv_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _i64, _i64, _i64, _f, _vp]),
     "lv_bias_scale_residual": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "lv_bias_scale_residual_layernorm": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _f, _vp]),
     "lv_patchify": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "lv_embed_tokens": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "lv_rope": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),

@@ -744,6 +744,18 @@ extern "C" int lv_bias_scale_residual(const void* x, const void* bias, const voi
                ? fail(LV_ELAUNCH, "lv_bias_scale_residual: launch failed") : LV_OK;
 }
 
+extern "C" int lv_bias_scale_residual_layernorm(const void* x, const void* bias, const void* ls, const void* residual, void* out,
+                                                void* normed, const void* gamma, const void* beta, int64_t rows, int h, float eps,
+                                                void* stream) {
+    if (!x || !ls || !residual || !out || !normed || !gamma || !beta) return fail(LV_EINVAL, "lv_bias_scale_residual_layernorm: null pointer");
+    if (rows < 0 || h <= 0 || h % 8 || h > 8192)
+        return fail(LV_EINVAL, "lv_bias_scale_residual_layernorm: rows=%lld h=%d (need h %% 8 == 0, h <= 8192)", (long long)rows, h);
+    if (!al16(x) || !al16(out) || !al16(normed) || !al16(ls) || !al16(residual) || !al16(gamma) || !al16(beta) || (bias && !al16(bias)))
+        return fail(LV_EINVAL, "lv_bias_scale_residual_layernorm: pointers must be 16-byte aligned");
+    return lv_launch_bsr_layernorm(x, bias, ls, residual, out, normed, gamma, beta, rows, h, eps, (hipStream_t)stream)
+               ? fail(LV_ELAUNCH, "lv_bias_scale_residual_layernorm: launch failed") : LV_OK;
+}
+
 extern "C" int lv_patchify(const void* img, void* patches, int n, int c, int height, int width, int patch, int kpad, void* stream) {
     if (!img || !patches) return fail(LV_EINVAL, "lv_patchify: null pointer");
     if (n < 0 || c <= 0 || patch <= 0 || height % patch || width % patch || kpad < c * patch * patch)

@@ -93,6 +93,8 @@ int lv_launch_layernorm_bwd(const void* x, const void* dy, const void* gamma, vo
                             int64_t rows, int h, int64_t x_rs, int64_t dy_rs, int64_t dx_rs, float eps, hipStream_t stream);
 int lv_launch_bias_scale_residual(const void* x, const void* bias, const void* ls, const void* res, void* out, int64_t rows, int h,
                                   hipStream_t stream);
+int lv_launch_bsr_layernorm(const void* x, const void* bias, const void* ls, const void* res, void* x1, void* y, const void* gamma,
+                            const void* beta, int64_t rows, int h, float eps, hipStream_t stream);
 int lv_launch_patchify(const void* img, void* out, int n, int c, int H, int W, int p, int kpad, hipStream_t stream);
 int lv_launch_embed_tokens(const void* proj, const void* conv_bias, const void* cls, const void* pos, void* out, int n, int np,
                            int ncls, int h, hipStream_t stream);

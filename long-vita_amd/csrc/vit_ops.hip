@@ -265,6 +265,86 @@ __global__ __launch_bounds__(256) void lv_bias_scale_residual_kernel(const __bf1
     }
 }
 
+// x1 = residual + (x + bias) * ls  AND  y = LayerNorm(x1) in one pass (intern_vit_model.py:59-66 and :74-77 followed by
+// the next sub-block's norm): one wave per row keeps the row in registers, so x1 is written but never read back.
+// x1 is rounded to bf16 before the statistics, exactly what the separate LayerNorm pass would read: results are
+// bit-identical to lv_bias_scale_residual followed by lv_layernorm.
+template <int CH>
+__global__ __launch_bounds__(256) void lv_bsr_layernorm_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ bias,
+                                                                const __bf16* __restrict__ ls, const __bf16* __restrict__ res,
+                                                                __bf16* __restrict__ x1, __bf16* __restrict__ y,
+                                                                const __bf16* __restrict__ gamma, const __bf16* __restrict__ beta,
+                                                                int64_t rows, int h, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const __bf16* xp = x + row * h;
+    const __bf16* rp = res + row * h;
+    __bf16* op = x1 + row * h;
+    float v[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < h) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(xp + col);
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(rp + col);
+            const bf16x8 sc = *reinterpret_cast<const bf16x8*>(ls + col);
+            bf16x8 b;
+            if (bias) b = *reinterpret_cast<const bf16x8*>(bias + col);
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float u = (float)t[i] + (bias ? (float)b[i] : 0.f);
+                o[i] = (__bf16)((float)r[i] + u * (float)sc[i]);
+                v[c][i] = (float)o[i];
+                s += v[c][i];
+            }
+            *reinterpret_cast<bf16x8*>(op + col) = o;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)h;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)h + eps);
+    __bf16* yp = y + row * h;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < h) {
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(gamma + col);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(beta + col);
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (__bf16)((v[c][i] - mean) * rstd * (float)g[i] + (float)b[i]);
+            *reinterpret_cast<bf16x8*>(yp + col) = o;
+        }
+    }
+}
+
+int lv_launch_bsr_layernorm(const void* x, const void* bias, const void* ls, const void* res, void* x1, void* y, const void* gamma,
+                            const void* beta, int64_t rows, int h, float eps, hipStream_t stream) {
+    if (rows == 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int ch = (h + 511) / 512;
+#define LV_BL(CH) hipLaunchKernelGGL((lv_bsr_layernorm_kernel<CH>), grid, block, 0, stream, (const __bf16*)x, (const __bf16*)bias, \
+                                     (const __bf16*)ls, (const __bf16*)res, (__bf16*)x1, (__bf16*)y, (const __bf16*)gamma,          \
+                                     (const __bf16*)beta, rows, h, eps)
+    if (ch <= 1) LV_BL(1); else if (ch <= 2) LV_BL(2); else if (ch <= 4) LV_BL(4); else if (ch <= 8) LV_BL(8); else LV_BL(16);
+#undef LV_BL
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 static unsigned stride_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (unsigned)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));

@@ -97,6 +97,28 @@ class InternViTTransformerLayer(torch.nn.Module):
         out = ops.bias_scale_residual(F.linear(act, mlp.linear_fc2.weight), mlp.linear_fc2.bias, self.ls2, x1)
         return out.view(s, b, h)
 
+    def forward_fused(self, hidden_states: torch.Tensor, normed: torch.Tensor, next_layer=None):
+        """The same layer without a graph (frozen tower), every LayerNorm folded into the pass that produces its input:
+        takes the layer input AND its input_layernorm output, returns (layer output, the NEXT layer's input_layernorm
+        of it, or None after the last layer).  Bit-identical to ``forward``."""
+        s, b, h = hidden_states.shape
+        hn = h // self.heads
+        sa, mlp = self.self_attention, self.mlp
+        qkv = F.linear(normed.view(s * b, h), sa.linear_qkv.weight, sa.linear_qkv.bias)
+        hv = qkv.view(s, b * self.heads, 3 * hn)
+        desc = ops.blocks_on_device([0, s], False, False, hidden_states.device)
+        ctx, _ = ops.attn_fwd_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], desc, 1.0 / math.sqrt(hn), False)
+        proj = F.linear(ctx.reshape(s * b, h), sa.linear_proj.weight)
+        x1, y = ops.bias_scale_residual_layernorm_launch(proj, sa.linear_proj.bias, self.ls1, hidden_states.view(s * b, h),
+                                                         self.pre_mlp_layernorm.weight, self.pre_mlp_layernorm.bias, self.eps)
+        act = ops.bias_gelu_launch(F.linear(y, mlp.linear_fc1.weight), mlp.linear_fc1.bias)
+        fc2 = F.linear(act, mlp.linear_fc2.weight)
+        if next_layer is None:
+            return ops.bias_scale_residual_launch(fc2, mlp.linear_fc2.bias, self.ls2, x1).view(s, b, h), None
+        out, nxt = ops.bias_scale_residual_layernorm_launch(fc2, mlp.linear_fc2.bias, self.ls2, x1, next_layer.input_layernorm.weight,
+                                                            next_layer.input_layernorm.bias, next_layer.eps)
+        return out.view(s, b, h), nxt.view(s, b, h)
+
 
 class _Decoder(torch.nn.Module):
     def __init__(self, cfg):
@@ -154,7 +176,15 @@ class InternViTModel(torch.nn.Module):
         patches = ops.patchify(x, cfg.patch_dim, wp.shape[1])
         proj = torch.matmul(patches, wp.t()).view(n, self.num_patches, cfg.hidden_size)
         tokens = ops.embed_tokens(proj, self.conv1.bias, self.class_token, self.position_embeddings.weight)
+        layers = list(self.decoder.layers)
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())) and layers:
+            # frozen tower: no graph, each LayerNorm rides on the pass that writes its input
+            first = layers[0]
+            normed = ops.layernorm_launch(tokens, first.input_layernorm.weight, first.input_layernorm.bias, first.eps)
+            for i, layer in enumerate(layers):
+                tokens, normed = layer.forward_fused(tokens, normed, layers[i + 1] if i + 1 < len(layers) else None)
+            return tokens.permute(1, 0, 2).contiguous()
         desc = ops.blocks_on_device([0, self.seq_length], False, False, x.device)
-        for layer in self.decoder.layers:
+        for layer in layers:
             tokens = layer(tokens, desc)
         return tokens.permute(1, 0, 2).contiguous()

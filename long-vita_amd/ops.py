@@ -790,6 +790,26 @@ def bias_scale_residual_launch(x: torch.Tensor, bias: torch.Tensor | None, ls: t
     return out
 
 
+def bias_scale_residual_layernorm_launch(x, bias, ls, residual, gamma, beta, eps: float):
+    """(out, normed) with out = residual + (x + bias) * ls and normed = LayerNorm(out; gamma, beta) in one pass (no
+    autograd): bit-identical to bias_scale_residual_launch followed by layernorm_launch, one read of out less."""
+    _bf16_2d(x, "bias_scale_residual_layernorm")
+    _bf16_2d(residual, "bias_scale_residual_layernorm (residual)")
+    if residual.shape != x.shape or residual.device != x.device:
+        raise LvAttnError("bias_scale_residual_layernorm: x and residual differ in shape or device")
+    x, residual = x.contiguous(), residual.contiguous()
+    h = x.shape[-1]
+    if h > 8192:
+        raise LvAttnError("bias_scale_residual_layernorm: rows wider than 8192 are not supported")
+    bias, ls = _vec(bias, "bias_scale_residual_layernorm bias", h, x, optional=True), _vec(ls, "LayerScale vector", h, x)
+    gamma, beta = _vec(gamma, "LayerNorm weight", h, x), _vec(beta, "LayerNorm bias", h, x)
+    out, normed = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().lv_bias_scale_residual_layernorm(_ptr(x), _ptr(bias), _ptr(ls), _ptr(residual), _ptr(out), _ptr(normed),
+                                                      _ptr(gamma), _ptr(beta), x.numel() // h, h, float(eps), _stream()),
+          "lv_bias_scale_residual_layernorm")
+    return out, normed
+
+
 class _BiasScaleResidual(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, ls, residual):

@@ -362,3 +362,39 @@ def test_full_size_tower_64_frames_24_layers():
         # the tower alone: [64, 1025, 1024]
         tower = m.vit(img)
         assert tower.shape == (64, 1025, 1024) and torch.isfinite(tower.float()).all()
+
+
+@pytest.mark.parametrize("rows,h", [(37, 1024), (9, 128), (5, 4096)])
+def test_bias_scale_residual_layernorm_is_the_two_passes_in_one(rows, h):
+    """out = residual + (x + bias) * ls and LayerNorm(out) from ONE pass equal the two separate kernels bit for bit
+    (the fused pass rounds `out` to bf16 before the statistics, as the second pass would read it)."""
+    from long_vita_amd import ops
+    x, res = _bf(rows, h, seed=1).cuda(), _bf(rows, h, seed=2, scale=2.0).cuda()
+    bias, ls = _bf(h, seed=3, scale=0.1).cuda(), _bf(h, seed=4, scale=0.3).cuda()
+    gamma, beta = _bf(h, seed=5).cuda(), _bf(h, seed=6, scale=0.2).cuda()
+    want_out = ops.bias_scale_residual_launch(x, bias, ls, res)
+    want_y = ops.layernorm_launch(want_out, gamma, beta, 1e-6)
+    out, y = ops.bias_scale_residual_layernorm_launch(x, bias, ls, res, gamma, beta, 1e-6)
+    assert torch.equal(out, want_out) and torch.equal(y, want_y)
+    out, y = ops.bias_scale_residual_layernorm_launch(x, None, ls, res, gamma, beta, 1e-6)
+    want_out = ops.bias_scale_residual_launch(x, None, ls, res)
+    assert torch.equal(out, want_out) and torch.equal(y, ops.layernorm_launch(want_out, gamma, beta, 1e-6))
+
+
+def test_frozen_tower_fused_loop_equals_layer_by_layer():
+    """The no-graph layer loop (LayerNorms folded into the passes that write their inputs) against the plain
+    layer-by-layer forward of the same module."""
+    from long_vita_amd import intern_vit as iv, ops
+    torch.manual_seed(5)
+    cfg = iv.InternViTConfig(num_layers=3, img_h=112, img_w=112)
+    m = iv.InternViTModel(cfg).to(torch.bfloat16).cuda()
+    img = _bf(2, 3, 112, 112, seed=9).cuda()
+    with torch.no_grad():
+        fused = m(img)
+        patches = ops.patchify(img, cfg.patch_dim, m._patch_weight().shape[1])
+        proj = torch.matmul(patches, m._patch_weight().t()).view(2, m.num_patches, cfg.hidden_size)
+        tokens = ops.embed_tokens(proj, m.conv1.bias, m.class_token, m.position_embeddings.weight)
+        desc = ops.blocks_on_device([0, m.seq_length], False, False, img.device)
+        for layer in m.decoder.layers:
+            tokens = layer(tokens, desc)
+    assert torch.equal(fused, tokens.permute(1, 0, 2).contiguous())
