@@ -24,11 +24,29 @@ typedef __attribute__((address_space(3))) char lds_char;
 #ifndef LV_RS_MAP
 #define LV_RS_MAP 1   // key block -> workgroup order: 0 = KV-head-major, 1 = KV head fastest (one head group per XCD)
 #endif
+#ifndef LV_RS_CFOLD
+#define LV_RS_CFOLD 1   // row constants ride in as the C operand of the S / dP products (see the kernel)
+#endif
+#ifndef LV_RS_DEPTH1
+#define LV_RS_DEPTH1 2   // one unit per iteration: how many iterations ahead the staging requests run
+#endif
+#ifndef LV_RS_DMA_FIRST
+#define LV_RS_DMA_FIRST 0   // staging requests at the start (1) or at the end (0) of the vector phase
+#endif
 #ifndef LV_RS_PRIO_M
 #define LV_RS_PRIO_M 2   // s_setprio level in the matrix phase
 #endif
 #ifndef LV_RS_PRIO_V
 #define LV_RS_PRIO_V 0   // s_setprio level in the vector phase
+#endif
+
+#ifdef LV_RS_STAMP
+// Diagnostic build only: per role (V-wave / K-wave) sums of shader-clock ticks spent in the vector work, waiting at the
+// barrier that ends it, in the matrix work, waiting at the barrier that ends that, plus iteration and wave counts.
+__device__ unsigned long long lv_rs_stamps[2][8];
+#define LV_STAMP(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#else
+#define LV_STAMP(var)
 #endif
 
 template <int D>
@@ -59,8 +77,9 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     constexpr int ROWB = D * 2;
     constexpr int CPR = D / 8;
     constexpr int QTILE = BQ * ROWB;   // bytes of a unit's Q (or dO) rows
-    constexpr int NBUF = 4 * NSL;      // ring slots: units of iterations it-1 .. it+2
-    constexpr int AHEAD = 2 * NSL;     // staging distance in units
+    constexpr int DEPTH = (NSL == 1) ? LV_RS_DEPTH1 : 2;   // staging distance in iterations
+    constexpr int NBUF = (DEPTH + 2) * NSL;   // ring slots: units of iterations it-1 .. it+DEPTH
+    constexpr int AHEAD = DEPTH * NSL;        // staging distance in units
     constexpr int SLOTB = 2 * QTILE + 256;        // [Q rows][dO rows][32 lse, 32 delta f32]
     constexpr int RPP = 64 / CPR;                 // rows per 1-KiB piece
     constexpr int PPW = (2 * QTILE / 1024) / NW;  // pieces per wave per unit: 2 (d=128) or 1 (d=64)
@@ -111,6 +130,19 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(bp + 16 * ks);
     }
+#if LV_RS_CFOLD
+    // The V-wave needs P = 2^(c S - lse2), the K-wave dS = P (dP - delta).  Both additions leave the vector phase:
+    // -lse2 (V-wave) / -delta (K-wave) of the unit's rows are the INITIAL accumulator of the S / dP product, and the
+    // factor c = scale * log2(e) is folded into the V-wave's K fragments once (one more bf16 rounding of K in the
+    // recomputed scores only: a relative 2^-9 on P, far inside the gradient tolerance; dK / dV use the unscaled data).
+    if (!is_k) {
+        const float cq = p.scale_log2e;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bfr[ks][e] = (__bf16)((float)bfr[ks][e] * cq);
+    }
+#endif
     // retire these loads now: inside the loop the only memory counter traffic is the staging
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bfr[ks]));
@@ -224,6 +256,28 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
         for (int i = 0; i < AHEAD; ++i) issue_dma();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         f32x16 x[NSL];
+        // row constants of a unit: -lse * log2(e) (V-wave) or -delta (K-wave) of rows 8g+4h .. +3
+        const float cmul = is_k ? -1.f : -1.4426950408889634f;
+#if LV_RS_CFOLD
+        // ... read straight into the accumulator the unit's S / dP product starts from
+        auto load_consts = [&](int u, int sbx) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t4 = *(LDS_PTR(f32x4, ld_ptr + sbx + 32 * g));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[u][4 * g + e] = t4[e] * cmul;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            load_consts(u, u * SLOTB);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 fa = *(LDS_PTR(bf16x8, a_ptr[ks] + u * SLOTB));
+                x[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x[u], 0, 0, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
 #pragma unroll
@@ -234,9 +288,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                 x[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bfr[ks], x[u], 0, 0, 0);
             }
         }
-        // row constants of a unit, read one matrix phase ahead: -lse * log2(e) (V-wave) or -delta (K-wave)
-        // of rows 8g+4h .. +3, so that the vector phase starts on registers, not on an LDS round trip
-        const float cmul = is_k ? -1.f : -1.4426950408889634f;
+        // ... read one matrix phase ahead, so that the vector phase starts on registers, not on an LDS round trip
         f32x4 cst[NSL][4];
         auto load_consts = [&](int u, int sbx) __attribute__((always_inline)) {
 #pragma unroll
@@ -248,14 +300,26 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
         };
 #pragma unroll
         for (int u = 0; u < NSL; ++u) load_consts(u, u * SLOTB);
+#endif
         bf16x8 y[NSL][2];
         int c_sl = nslice - 1, c_hg = 0;  // (slice, head) of the next unit
         int c_n = 0;                      // units consumed so far
         int sb = 0;                       // ring byte offset of this iteration's first unit
         if (is_k) asm volatile("s_barrier" ::: "memory");
+#ifdef LV_RS_STAMP
+        uint64_t st_vec = 0, st_bar1 = 0, st_mat = 0, st_bar2 = 0;
+#endif
         for (int it = 0; it < niter; ++it) {
             const int sb_next = (sb + NSL * SLOTB == NBUF * SLOTB) ? 0 : sb + NSL * SLOTB;
+            LV_STAMP(ta);
             // ================= VALU(it) =================
+#if LV_RS_DMA_FIRST
+            // units of iteration it+2 (their slots held iteration it-2, whose last reader finished two barriers ago),
+            // requested while the last matrix phase's results are still on their way to the registers
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) issue_dma();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int u = 0; u < NSL; ++u) {
                 const int i0 = c_sl * BQ;  // first query row of the unit, relative to q_row0
@@ -266,7 +330,11 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                     const bool need_mask = dead_unit || (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
                     float pv[16];
 #pragma unroll
+#if LV_RS_CFOLD
+                    for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(x[u][i]);
+#else
                     for (int i = 0; i < 16; ++i) pv[i] = fast_exp2(__builtin_fmaf(x[u][i], c, cst[u][i >> 2][i & 3]));
+#endif
                     if (need_mask) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
@@ -286,27 +354,42 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                     pf[1] = *(LDS_PTR(bf16x8, p_ptr + u * PBUF + 1024));
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
+#if LV_RS_CFOLD
+                        y[u][i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * x[u][i]);  // (bf16 -> f32 is exact)
+#else
                         y[u][i >> 3][i & 7] = (__bf16)((float)pf[i >> 3][i & 7] * (x[u][i] + cst[u][i >> 2][i & 3]));  // (bf16 -> f32 is exact)
+#endif
                 }
                 asm volatile("" : "+v"(y[u][0]), "+v"(y[u][1]));  // Y is formed here, not next to its first use
             }
+#if !LV_RS_DMA_FIRST
             // units of iteration it+2; their slots held iteration it-2, whose last reader finished two barriers ago
 #pragma unroll
             for (int u = 0; u < NSL; ++u) issue_dma();
+#endif
             __builtin_amdgcn_sched_barrier(0);
+            LV_STAMP(tb);
             // leave this iteration's requests in flight, everything older has landed
-            if (c_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSL * PPW + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSL * PPW) : "memory");
+            if (c_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((DEPTH - 1) * (NSL * PPW + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((DEPTH - 1) * NSL * PPW) : "memory");
             __builtin_amdgcn_sched_barrier(0);
 
             // ================= MFMA(it): X of the next iteration's units and acc += A_cols^T Y =================
+            LV_STAMP(tc);
             __builtin_amdgcn_s_setprio(LV_RS_PRIO_M);
+#if LV_RS_CFOLD
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) load_consts(u, sb_next + u * SLOTB);   // x of the next units starts from their row constants
+            load_group(0, 0, sb_next, sb);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NSL + XPG + 2 * APG, 0);
+#else
 #pragma unroll
             for (int u = 0; u < NSL; ++u)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x[u][i] = 0.f;
             load_group(0, 0, sb_next, sb);
             __builtin_amdgcn_sched_group_barrier(0x100, XPG + 2 * APG, 0);
+#endif
 #pragma unroll
             for (int gg = 0; gg < NGT; ++gg) {
                 const int set = gg & 1;
@@ -334,14 +417,32 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * XPG, 0);
                 }
             }
+#if !LV_RS_CFOLD
 #pragma unroll
             for (int u = 0; u < NSL; ++u) load_consts(u, sb_next + u * SLOTB);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(LV_RS_PRIO_V);
+#ifdef LV_RS_STAMP
+            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(x[0][0]));   // the matrix work's results have to exist here
+#endif
+            LV_STAMP(td);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            LV_STAMP(te);
+#ifdef LV_RS_STAMP
+            st_vec += tb - ta; st_bar1 += tc - tb; st_mat += td - tc; st_bar2 += te - td;
+#endif
             sb = sb_next;
         }
+#ifdef LV_RS_STAMP
+        if (lane == 0 && (w == 0 || w == 4)) {
+            unsigned long long* o = lv_rs_stamps[is_k ? 1 : 0];
+            atomicAdd(o + 0, (unsigned long long)st_vec); atomicAdd(o + 1, (unsigned long long)st_bar1);
+            atomicAdd(o + 2, (unsigned long long)st_mat); atomicAdd(o + 3, (unsigned long long)st_bar2);
+            atomicAdd(o + 4, (unsigned long long)niter); atomicAdd(o + 5, 1ull);
+        }
+#endif
         if (!is_k) asm volatile("s_barrier" ::: "memory");
     }
     // no staging request may outlive the workgroup: its LDS could already belong to another one
@@ -388,7 +489,8 @@ void lv_select_rs_units(int n) { g_rs_units = (n == 1) ? 1 : 2; }
 template <int D, int NSL>
 static void launch_rs(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8)), block(512);
-    size_t lds = (size_t)4 * NSL * (2 * 32 * D * 2 + 256) + (size_t)NSL * 4 * 2048;  // ring slots + P buffers
+    constexpr int depth = (NSL == 1) ? LV_RS_DEPTH1 : 2;
+    size_t lds = (size_t)(depth + 2) * NSL * (2 * 32 * D * 2 + 256) + (size_t)NSL * 4 * 2048;  // ring slots + P buffers
     if (causal) {
         if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, true, NSL>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((lv_bwd_dkdv_rs_kernel<D, true, false, NSL>), grid, block, lds, stream, p);
@@ -405,3 +507,14 @@ int lv_launch_bwd_dkdv_rs(const BwdParams& p, int d, int causal, int accum, hipS
     else { if (two) launch_rs<64, 2>(p, causal, accum, stream); else launch_rs<64, 1>(p, causal, accum, stream); }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+#ifdef LV_RS_STAMP
+extern "C" int lv_debug_rs_stamps(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lv_rs_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lv_rs_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
