@@ -415,7 +415,7 @@ def main():
         achieved = flops_per_gpu_step / mean_kernel_s / 1e12
         traffic, traffic_note = None, None
         if wl == "prefill_1m" and not args.seq and world == 1:
-            traffic, traffic_note = profiled_traffic("r01_prefill_1m_pmc_summary.json", "lv_fwd_pp_kernel<128, true>")
+            traffic, traffic_note = profiled_traffic("r02_prefill_1m_pmc_summary.json", "lv_fwd_pp_kernel<128, true, false>")
         res = {
             "metric": ("attention prefill tokens/sec (node) at 1M ctx" if not args.seq else f"attention prefill tokens/sec (node) at {S} ctx")
             if wl == "prefill_1m" else f"attention tokens/sec ({wl})",
@@ -446,7 +446,7 @@ def main():
         except Exception as e:      # diagnostic only
             res["mfma_clock_mhz"] = {"error": str(e)}
         res["host_cpus"] = os.cpu_count()
-        if not args.no_cpu_baseline and wl == "prefill_1m":
+        if not args.no_cpu_baseline and wl == "prefill_1m" and world == 1:     # the host baseline is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(config["seq_len"])
             if world == 1 and not args.seq:
                 res["cpu_baseline"]["cfg1_full"] = cpu_baseline_cfg1()
