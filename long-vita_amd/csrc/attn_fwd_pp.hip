@@ -25,6 +25,9 @@
 
 typedef __attribute__((address_space(3))) char lds_char;
 
+#ifndef LV_PP_NS
+#define LV_PP_NS 3
+#endif
 #ifndef LV_PP_PRIO
 #define LV_PP_PRIO 2   // s_setprio level of a wave in its matrix phase (0 in the vector phase)
 #endif
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
     constexpr int ROWB = D * 2;       // bytes per K/V row
     constexpr int TILEB = BN * ROWB;  // bytes per K or V tile
     constexpr int CPR = D / 8;        // 16-byte chunks per row
-    constexpr int NS = 3;             // ring slots
+    constexpr int NS = LV_PP_NS;      // ring slots: tiles are requested NS - 1 ahead of the tile being consumed
     constexpr int SLOTB = 2 * TILEB;  // [K tile][V tile]
     constexpr int RPP = 64 / CPR;     // rows per 1-KiB piece (one wave-instruction of the staging)
     constexpr int PPW = (TILEB / 1024) / 4;  // pieces per wave per tile: 4 (d=128) or 2 (d=64)
@@ -227,8 +230,8 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 
     if (nkt > 0) {
         // prologue: tiles 0 and 1 of this group's operand, then S_0 (both groups at once)
-        issue_tile();
-        issue_tile();
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) issue_tile();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         qk(0);
         int sb = 0;  // byte offset of the slot of the NEXT matrix phase
@@ -306,9 +309,9 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) pf[st][s2][i] = (__bf16)0.f;
             }
-            issue_tile();  // K (group A) or V (group B) tile t + 2
+            issue_tile();  // K (group A) or V (group B) tile t + NS - 1
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PPW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NS - 2) * PPW) : "memory");
             __builtin_amdgcn_sched_barrier(0);
 
             // ================= MFMA(t+1): S_{t+1} = K_{t+1} Q^T, O += V_t P_t =================
@@ -411,7 +414,7 @@ static void launch_pp(const FwdParams& p0, int causal, hipStream_t stream) {
     dim3 grid(p.head_per_xcd ? (unsigned)(((p.hkv + 7) / 8) * 8 * p.n_blocks * p.group)
                              : (unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(512);
 #endif
-    size_t lds = (size_t)3 * 2 * 64 * D * 2;  // 3 slots x (K tile + V tile)
+    size_t lds = (size_t)LV_PP_NS * 2 * 64 * D * 2;  // ring slots x (K tile + V tile)
     if constexpr (D == 128) {
         if (p.rope_cos) {
             if (causal) hipLaunchKernelGGL((lv_fwd_pp_kernel<D, true, true>), grid, block, lds, stream, p);
