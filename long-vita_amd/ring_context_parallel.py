@@ -41,14 +41,16 @@ class HipBackend:
     def block_fwd(self, q3, k3, v3, qr, kr, causal, shift, scale, out_blk, lse_blk, rope=None):
         desc = self.ops.rect_blocks_on_device(qr[0], qr[1], kr[0], kr[1], causal, shift, False, q3.device)
         if rope is not None:    # unrotated queries, rotated in the kernel's prologue
-            self.ops.attn_fwd_rope_launch(q3, k3, v3, desc, scale, causal, rope[0], rope[1], out=out_blk, lse=lse_blk)
+            self.ops.attn_fwd_rope_launch(q3, k3, v3, desc, scale, causal, rope[0], rope[1], out=out_blk, lse=lse_blk,
+                                          q_rot=rope[2] if len(rope) > 2 else None)
         else:
             self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, causal, out_blk, lse_blk)
 
     def block_fwd_rects(self, q3, k3, v3, rects, scale, out_blk, lse_blk, rope=None):
         desc = self.ops.rects_blocks_on_device(rects, False, q3.device)
         if rope is not None:
-            self.ops.attn_fwd_rope_launch(q3, k3, v3, desc, scale, True, rope[0], rope[1], out=out_blk, lse=lse_blk)
+            self.ops.attn_fwd_rope_launch(q3, k3, v3, desc, scale, True, rope[0], rope[1], out=out_blk, lse=lse_blk,
+                                          q_rot=rope[2] if len(rope) > 2 else None)
         else:
             self.ops.attn_fwd_launch(q3, k3, v3, desc, scale, True, out_blk, lse_blk)
 
@@ -227,12 +229,14 @@ class RingAttention:
                 be.block_bwd(q3, k3, v3, out3, dout3, lse, delta, (q0, ql), (k0, kl), True, sh, scale, dq_acc, dk_acc, dv_acc)
 
     # -- forward -----------------------------------------------------------
-    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False, cu_seqlens=None, rope=None):
+    def forward(self, q, k, v, n_heads: int, scale: float | None = None, return_state: bool = False, cu_seqlens=None, rope=None,
+                q_rot_out=None):
         """q [s, b, Hq*d], k/v [s, b, Hkv*d] (local zig-zag shard) -> out [s, b, Hq*d].  With ``cu_seqlens`` (global
         segment boundaries, b == 1) attention stays inside the packed segments.  With ``rope`` = (cos, sin), bf16 tables
         [s, d] for THIS rank's rows (the zig-zag slice of the table, rotary_pos_embedding.py:36-47; b == 1), q and k come
         UNROTATED: the keys are rotated while they are packed into the ring message, the queries inside the block
-        kernels (forward only: the prefill path)."""
+        kernels.  ``q_rot_out`` ([s, Hq, d] bf16, optional) receives the rotated queries from the launches of step 0,
+        which between them visit every local row (what a backward pass needs)."""
         be = self._be()
         s_loc, b, hq_d = q.shape
         d = hq_d // n_heads
@@ -263,6 +267,7 @@ class RingAttention:
             kv[0][0].copy_(k.reshape(s_loc, b * hkv, d))
             kv[0][1].copy_(v.reshape(s_loc, b * hkv, d))
         rkw = {} if rope is None else {"rope": rope}
+        rope0 = rope if (rope is None or q_rot_out is None) else (rope[0], rope[1], q_rot_out)    # step 0 also writes q_rot
         lse_acc = torch.empty((b * n_heads, s_loc), dtype=torch.float32, device=dev)   # returned (saved for backward)
         packed = cu_seqlens is not None
         if packed:      # rows are first touched by different chunk pairs: start from the neutral element
@@ -280,13 +285,14 @@ class RingAttention:
                 t0 = torch.cuda.Event(enable_timing=True); t0.record()
             if not packed:
                 qr, kr, causal, shift = self.step_rect(step, s_loc)
-                be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk, **rkw)
+                be.block_fwd(q3, cur[0], cur[1], qr, kr, causal, shift, scale, out_blk, lse_blk,
+                             **(rkw if step else ({} if rope0 is None else {"rope": rope0})))
                 # step 0 covers every local row: it initialises the running result instead of merging into it
                 be.merge(out_acc, lse_acc, out_blk, lse_blk, qr[0], qr[1], init=(step == 0))
             else:
                 for rects in self.segment_rects(step, s_loc, cu_seqlens):
                     if rects:
-                        self._fwd_rects(be, q3, cur[0], cur[1], rects, scale, out_blk, lse_blk, rope)
+                        self._fwd_rects(be, q3, cur[0], cur[1], rects, scale, out_blk, lse_blk, rope if step else rope0)
                         lo = min(r[0] for r in rects)
                         hi = max(r[0] + r[1] for r in rects)
                         be.merge(out_acc, lse_acc, out_blk, lse_blk, lo, hi - lo)
@@ -392,17 +398,71 @@ class _RingAttnFunction(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+def ring_rope_forward(engine, q, k, v, n_heads, scale, cos_tab, sin_tab, cu_seqlens=None, for_backward=True):
+    """Ring forward on UNROTATED q / k [s, 1, heads*d] with the rotary embedding folded in (keys rotated while they are
+    packed into the ring message, queries inside the block kernels).  Returns (out, lse, q_rot, k_rot); the last two
+    (what the backward kernels read) only when ``for_backward``."""
+    from . import ops
+    s_loc, b, hq_d = q.shape
+    if b != 1:
+        raise ValueError("the fused rotary embedding on the ring needs micro-batch 1")
+    d = hq_d // n_heads
+    q_rot = torch.empty((s_loc, n_heads, d), dtype=q.dtype, device=q.device) if for_backward else None
+    out, lse = engine.forward(q, k, v, n_heads, scale, return_state=True, cu_seqlens=cu_seqlens, rope=(cos_tab, sin_tab),
+                              q_rot_out=q_rot)
+    # the ring buffers are reused by the steps: the rotated keys are made once more for the backward (a bandwidth-bound
+    # pass over K, a fifth of the pass over Q that the fusion removes)
+    k_rot = ops.rope_launch(k.reshape(s_loc, -1, d), cos_tab, sin_tab) if for_backward else None
+    return out, lse, q_rot, k_rot
+
+
+def ring_rope_backward(engine, q_rot, k_rot, v, out, lse, dout, n_heads, scale, cos_tab, sin_tab, cu_seqlens=None):
+    """Gradients w.r.t. the UNROTATED q, k (and v): the ring backward on the rotated operands, then the transposed
+    rotation of dq and dk in place."""
+    from . import ops
+    s_loc, hq, d = q_rot.shape
+    dq, dk, dv = engine.backward(q_rot.view(s_loc, 1, hq * d), k_rot.view(s_loc, 1, -1), v, out, lse, dout.contiguous(),
+                                 n_heads, scale, cu_seqlens=cu_seqlens)
+    dq3, dk3 = dq.view(s_loc, hq, d), dk.view(s_loc, -1, d)
+    ops.rope_launch(dq3, cos_tab, sin_tab, conj=True, out=dq3)
+    ops.rope_launch(dk3, cos_tab, sin_tab, conj=True, out=dk3)
+    return dq, dk, dv
+
+
+class _RingRopeAttnFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, engine, n_heads, scale, cos_tab, sin_tab, cu_seqlens=None):
+        need_bwd = any(ctx.needs_input_grad[:3])
+        out, lse, q_rot, k_rot = ring_rope_forward(engine, q, k, v, n_heads, scale, cos_tab, sin_tab, cu_seqlens, need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(q_rot, k_rot, v, out, lse, cos_tab, sin_tab)
+        ctx.engine, ctx.n_heads, ctx.scale, ctx.cu_seqlens = engine, n_heads, scale, cu_seqlens
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_rot, k_rot, v, out, lse, cos_tab, sin_tab = ctx.saved_tensors
+        dq, dk, dv = ring_rope_backward(ctx.engine, q_rot, k_rot, v, out, lse, dout, ctx.n_heads, ctx.scale, cos_tab, sin_tab,
+                                        ctx.cu_seqlens)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
 _engines: dict = {}
 
 
 def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask=None, dropout_p=0.,
-                              actual_seq_qlen=None, actual_seq_kvlen=None):
+                              actual_seq_qlen=None, actual_seq_kvlen=None, rope=None):
     """Drop-in for mindspeed.core.context_parallel.ring_context_parallel.ringattn_context_parallel
     as called at dot_product_attention.py:70-71.
 
     ``cp_para`` keys read: causal, cp_group, cp_size, rank, cp_global_ranks (the double-ring
     window keys cp_inner_ranks / cp_outer_ranks / ... are accepted and must describe a single
-    ring: one 8-GPU node has no inter-node window), pse must be None."""
+    ring: one 8-GPU node has no inter-node window), pse must be None.
+
+    ``rope`` = (cos, sin) (not in the reference's signature: its rotary embedding is applied by the caller, with the
+    scripts' --use-fused-rotary-pos-emb by a fused NPU op): bf16 tables [s_local, d] for THIS rank's rows
+    (rotary_pos_embedding.py:36-47); q and k then come UNROTATED and the rotation happens inside the ring
+    (differentiable; results bit-identical to rotating first)."""
     if dropout_p not in (0, 0.0):
         raise NotImplementedError("attention dropout is not supported on the ring path (the shipped scripts use 0)")
     if cp_para.get("pse") is not None:
@@ -431,6 +491,8 @@ def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask
         _engines[key] = eng
     d = q.shape[-1] // n
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
+    if rope is not None:
+        return _RingRopeAttnFunction.apply(q, k, v, eng, n, float(scale), rope[0], rope[1], cu_seqlens)
     return _RingAttnFunction.apply(q, k, v, eng, n, float(scale), cu_seqlens)
 
 

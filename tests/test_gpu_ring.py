@@ -342,3 +342,79 @@ def test_full_size_ring_backward_rank_equals_single_launch_1m():
     err = (dq.reshape(s_loc, Hq, D).float() - want).abs().max().item()
     assert err <= REL_TOL * want.abs().max().item(), err
     assert torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all()
+
+
+def _rope_case(S, seed):
+    from oracle import rope_ref as R
+    Hq, Hkv, D = 10, 2, 128
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(S, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, Hq, D, generator=g).to(torch.bfloat16)
+    ang = torch.from_numpy(R.angle_table(S, D, 1000000)).reshape(S, D)
+    return Hq, Hkv, D, q, k, v, do, torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("cp,cu", [(2, None), (4, [0, 700, 2100, 2101, 3900, 4096])])
+def test_ring_rope_forward_backward_equals_rotating_first(cp, cu):
+    """The ring with the rotary embedding folded in (ring_rope_forward / ring_rope_backward, what the autograd function
+    of ringattn_context_parallel(rope=...) runs) against the plain ring on q / k rotated beforehand with the transposed
+    rotation applied to its dq / dk afterwards: out, lse and dq / dk / dv bit for bit, over virtual ranks."""
+    from long_vita_amd import ops
+    from long_vita_amd.ring_context_parallel import RingAttention, ring_rope_backward, ring_rope_forward
+    S = 4096 if cu else 1024 * cp
+    Hq, Hkv, D, q, k, v, do, cos_all, sin_all = _rope_case(S, 17 + cp)
+    scale = A.default_scale(D)
+    fabric = LoopbackFabric(cp)
+    dev = torch.device("cuda", 0)
+    cus = None if cu is None else tuple(cu)
+
+    def body(r):
+        torch.cuda.set_device(0)
+        s_loc = S // cp
+        cos_l, sin_l = zigzag_local(cos_all, cp, r).contiguous().to(dev), zigzag_local(sin_all, cp, r).contiguous().to(dev)
+        ql, kl, vl, dl = (zigzag_local(x, cp, r).reshape(s_loc, 1, -1).to(dev) for x in (q, k, v, do))
+        eng = RingAttention(None, cp, r, causal=True, comm=LoopbackComm(fabric, r))
+        out, lse, q_rot, k_rot = ring_rope_forward(eng, ql, kl, vl, Hq, scale, cos_l, sin_l, cus)
+        dq, dk, dv = ring_rope_backward(eng, q_rot, k_rot, vl, out, lse, dl, Hq, scale, cos_l, sin_l, cus)
+        fused = [t.clone() for t in (out, lse, dq, dk, dv)]
+        qr = ops.rope_launch(ql.view(s_loc, Hq, D), cos_l, sin_l).view(s_loc, 1, -1)
+        kr = ops.rope_launch(kl.view(s_loc, Hkv, D), cos_l, sin_l).view(s_loc, 1, -1)
+        assert torch.equal(qr.view(s_loc, Hq, D), q_rot) and torch.equal(kr.view(s_loc, Hkv, D), k_rot)
+        out2, lse2 = eng.forward(qr, kr, vl, Hq, scale, return_state=True, cu_seqlens=cus)
+        dq2, dk2, dv2 = eng.backward(qr, kr, vl, out2, lse2, dl, Hq, scale, cu_seqlens=cus)
+        dq2 = ops.rope_launch(dq2.view(s_loc, Hq, D), cos_l, sin_l, conj=True).view(s_loc, 1, -1)
+        dk2 = ops.rope_launch(dk2.view(s_loc, Hkv, D), cos_l, sin_l, conj=True).view(s_loc, 1, -1)
+        torch.cuda.synchronize()
+        return all(torch.equal(a, b) for a, b in zip(fused, (out2, lse2, dq2, dk2, dv2)))
+    assert all(run_virtual_ranks(cp, body))
+
+
+def test_ring_rope_autograd_entry_point_single_rank():
+    """ringattn_context_parallel(..., rope=(cos, sin)) under torch autograd (one rank: the autograd engine runs every
+    backward of a device on one thread, so virtual ranks cannot exchange inside it) against apply-rope-first through the
+    same entry point, packed segments included: out and the gradients of the unrotated q, k, v bit for bit."""
+    from long_vita_amd import ops
+    from long_vita_amd.ring_context_parallel import ringattn_context_parallel
+    S = 1536
+    Hq, Hkv, D, q, k, v, do, cos_all, sin_all = _rope_case(S, 31)
+    dev = torch.device("cuda", 0)
+    cos_l, sin_l = cos_all.to(dev), sin_all.to(dev)
+    scale = A.default_scale(D)
+    para = {"causal": True, "cp_group": None, "cp_size": 1, "rank": 0, "cp_global_ranks": [0]}
+    for ends in (None, [300, 301, 1000, 1536]):
+        res = []
+        for fused in (True, False):
+            ql, kl, vl = (x.to(dev).requires_grad_(True) for x in (q, k, v))
+            if fused:
+                out = ringattn_context_parallel(ql.view(S, 1, -1), kl.view(S, 1, -1), vl.view(S, 1, -1), Hq, para, scale,
+                                                None, 0., ends, ends, rope=(cos_l, sin_l))
+            else:
+                qr, kr = ops.rope(ql, cos_l, sin_l), ops.rope(kl, cos_l, sin_l)
+                out = ringattn_context_parallel(qr.view(S, 1, -1), kr.view(S, 1, -1), vl.view(S, 1, -1), Hq, para, scale,
+                                                None, 0., ends, ends)
+            out.backward(do.to(dev).view(S, 1, -1))
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), ql.grad.clone(), kl.grad.clone(), vl.grad.clone()))
+        assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), ends
