@@ -368,7 +368,6 @@ def main():
     else:  # cfg2_vit: 24 layers x 64 frames x 16 heads x 1025 tokens, d=64, non-causal
         B, H, Sv, Dv, layers = 64, 16, 1025, 64, 24
         qkv = [rnd(Sv, B * H, Dv) for _ in range(3)]
-        desc = ops.blocks_on_device([0, Sv], False, False, dev)
         out = torch.empty_like(qkv[0])
         lse = torch.empty((B * H, Sv), dtype=torch.float32, device=dev)
         scale = 1.0 / math.sqrt(Dv)
@@ -377,7 +376,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(layers):
-                ops.attn_fwd_launch(qkv[0], qkv[1], qkv[2], desc, scale, False, out, lse)
+                ops.attn_fwd_dense_launch(qkv[0], qkv[1], qkv[2], scale, False, out, lse)
             e1.record()
             return e0, e1
         tokens_per_step = B * Sv

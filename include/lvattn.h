@@ -98,6 +98,21 @@ int lvattn_fwd(const void* q, const void* k, const void* v, void* out, float* ls
                int64_t o_row_stride, int64_t o_head_stride,
                int64_t lse_stride, float softmax_scale, int causal, void* stream);
 
+/* lvattn_fwd for ONE dense segment without descriptors: q_rows query rows against k_rows keys, every head.  Replaces
+ * the same call sites where the reference has no packing: the vision tower's dot_product_attention.py:314-325
+ * (q = k = v rows [1025], batch x heads as the head axis, causal = 0) and a single-sequence causal prefill
+ * (:454-467).  With causal = 1 the rule is aligned to the END of both ranges (row i sees keys
+ * j <= i + k_rows - q_rows; k_rows >= q_rows).  The kernels number their work items themselves, and the workgroup
+ * size follows the row count (the tower's 1025 rows run as 9 workgroups of 128 rows instead of 4 of 256 plus one
+ * that holds 8 waves for a single row).  Same tensors, strides, lse and errors as lvattn_fwd. */
+int lvattn_fwd_dense(const void* q, const void* k, const void* v, void* out, float* lse,
+                     int q_rows, int k_rows, int hq, int hkv, int d,
+                     int64_t q_row_stride, int64_t q_head_stride,
+                     int64_t k_row_stride, int64_t k_head_stride,
+                     int64_t v_row_stride, int64_t v_head_stride,
+                     int64_t o_row_stride, int64_t o_head_stride,
+                     int64_t lse_stride, float softmax_scale, int causal, void* stream);
+
 /* Tuning / test hook, no counterpart in the reference: choose the forward kernel for later lvattn_fwd calls of this
  * process ("default", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
  * is read on first use otherwise).  Not thread-safe against concurrent launches. */

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
     constexpr int CPR = D / 8;        // 16-byte chunks per row
     constexpr int NT = NW * 64;       // threads per workgroup
     constexpr int NLD = (BN * CPR) / NT;  // 16-byte loads per thread per tile
+    static_assert(NLD * NT == BN * CPR, "the threads share a tile's 16-byte pieces evenly");
     constexpr float RESCALE_LOG2 = 8.0f;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
     }
     const int head = kvh * p.group + hg;
 
-    const AttnDesc dsc = p.desc[blk];
+    const AttnDesc dsc = lv_fwd_desc(p, blk, NW * 32, CAUSAL);
     const int q_row0 = dsc.a_row0, q_rows = dsc.a_rows;
     const int k_row0 = dsc.b_row0, k_len = dsc.b_len;
     const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
@@ -105,27 +106,25 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
         st_voff[i] = (int)(row * p.v_rs * 2) + ch * 16;
     }
     const int rows_avail = min(k_len, p.k_rows_total - k_row0);  // key rows that exist from k_row0 on
-    u32x4 kreg[NLD], vreg[NLD];
-    auto issue_loads = [&](int t) {
+    // K and V of the next tile share ONE set of staging registers: K is requested at the top of a tile and written to
+    // the other LDS buffer as soon as the S product has been issued, V is requested then and written at the end.
+    u32x4 sreg[NLD];
+    auto issue_loads = [&](int t, bool second) {
         int rows = rows_avail - t * BN;
         rows = rows < 0 ? 0 : (rows > BN ? BN : rows);
         // num_records: whole rows of this tile (the last row only up to the end of the head's columns)
-        uint32_t krec = rows ? (uint32_t)((rows - 1) * p.k_rs * 2 + ROWB) : 0u;
-        uint32_t vrec = rows ? (uint32_t)((rows - 1) * p.v_rs * 2 + ROWB) : 0u;
-        auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(kbase + t * k_tile_bytes), 0, krec, 0x00020000);
-        auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(vbase + t * v_tile_bytes), 0, vrec, 0x00020000);
+        const int64_t rs = second ? p.v_rs : p.k_rs;
+        uint32_t rec = rows ? (uint32_t)((rows - 1) * rs * 2 + ROWB) : 0u;
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(second ? vbase + t * v_tile_bytes : kbase + t * k_tile_bytes), 0, rec, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, st_koff[i], 0, 0));
-            vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, st_voff[i], 0, 0));
-        }
+        for (int i = 0; i < NLD; ++i)
+            sreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, second ? st_voff[i] : st_koff[i], 0, 0));
     };
-    auto write_lds = [&](int buf) {
+    auto write_lds = [&](int buf, bool second) {
+        lds_char* const dst = (second ? ldsV : ldsK) + buf * TILEB;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            *(LDS_PTR(u32x4, ldsK + buf * TILEB + st_lds[i])) = kreg[i];
-            *(LDS_PTR(u32x4, ldsV + buf * TILEB + st_lds[i])) = vreg[i];
-        }
+        for (int i = 0; i < NLD; ++i)
+            *(LDS_PTR(u32x4, dst + st_lds[i])) = sreg[i];
     };
 
     // ---- LDS read addresses
@@ -154,8 +153,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
     const float c = p.scale_log2e;
 
     if (nkt > 0) {
-        issue_loads(0);
-        write_lds(0);
+        issue_loads(0, false);
+        write_lds(0, false);
+        issue_loads(0, true);
+        write_lds(0, true);
     }
     // Retire the Q loads here: otherwise the compiler waits for them inside the loop with
     // vmcnt(7..0) in front of the first MFMAs of every tile, which also drains the K/V
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
     auto tile = [&](int t, auto cur_c) {
         constexpr int cur = decltype(cur_c)::value;
         const bool more = (t + 1 < nkt);
-        if (more) issue_loads(t + 1);
+        if (more) issue_loads(t + 1, false);
 
         if (t < my_nkt) {
             // ---- S^T = K Q^T, two 32-key sub-tiles
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
                     s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
                 }
             }
+            if (more) { write_lds(cur ^ 1, false); issue_loads(t + 1, true); }
             // ---- mask (only tiles that cross the causal diagonal or the key-range end)
             const int kb0 = t * BN;
             const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len);
@@ -246,7 +248,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
                     }
                 }
         }
-        if (more) write_lds(cur ^ 1);
+        if (more) {
+            if (t >= my_nkt) { write_lds(cur ^ 1, false); issue_loads(t + 1, true); }   // a wave with no rows here only stages
+            write_lds(cur ^ 1, true);
+        }
         __syncthreads();
     };
     for (int t = 0; t < nkt; t += 2) {

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 #endif
     const int head = kvh * p.group + hg;
 
-    const AttnDesc dsc = p.desc[blk];
+    const AttnDesc dsc = lv_fwd_desc(p, blk, 256, CAUSAL);
     const int q_row0 = dsc.a_row0, q_rows = dsc.a_rows;
     const int k_row0 = dsc.b_row0, k_len = dsc.b_len;
     const int shift = CAUSAL ? dsc.shift : 0x3fffffff;

@@ -175,6 +175,9 @@ static int check_common(const void* q, const void* k, const void* v, int hq, int
     if (hq <= 0 || hkv <= 0 || hq % hkv) return fail(LV_EINVAL, "hq=%d must be a positive multiple of hkv=%d", hq, hkv);
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return fail(LV_EINVAL, "q/k/v must be 16-byte aligned");
     if ((q_rs | q_hs | k_rs | k_hs | v_rs | v_hs) & 7) return fail(LV_EINVAL, "row/head strides must be multiples of 8 elements");
+    // the kernels address the rows of one tile (at most 256) with 32-bit byte offsets from the tile's first row
+    const int64_t rs_max = std::max(std::max(q_rs, k_rs), v_rs), rs_min = std::min(std::min(q_rs, k_rs), v_rs);
+    if (rs_min < 0 || rs_max * 2 * 256 > 0x7fffffffLL) return fail(LV_EINVAL, "row stride %lld elements out of range", (long long)(rs_min < 0 ? rs_min : rs_max));
     return 0;
 }
 
@@ -192,12 +195,30 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
                     const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
                     int hq, int hkv, int d,
                     int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
-                    int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream, const RopeArgs* rope) {
+                    int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream, const RopeArgs* rope,
+                    bool dense = false) {
     if (int e = check_common(q, k, v, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
-    if (!out || !lse || !desc_dev) return fail(LV_EINVAL, "null out/lse/desc pointer");
+    if (!out || !lse || (!desc_dev && !dense)) return fail(LV_EINVAL, "null out/lse/desc pointer");
     if (((uintptr_t)out & 7) || (o_rs & 3) || (o_hs & 3)) return fail(LV_EINVAL, "out must be 8-byte aligned with strides % 4 == 0");
     if (n_blocks < 0 || q_rows_total <= 0 || k_rows_total <= 0) return fail(LV_EINVAL, "bad sizes");
     if (lse_stride < q_rows_total) return fail(LV_EINVAL, "lse_stride %lld < q_rows_total %d", (long long)lse_stride, q_rows_total);
+    // One dense segment: the kernels number their work items themselves (lv_fwd_desc), so the launch needs no
+    // descriptor memory and its workgroups can be sized to the row count.  A workgroup holds its wave slots for a
+    // whole key sweep however few rows it has, so the lockstep kernel runs in 4-wave workgroups (128 rows) when that
+    // needs fewer wave slots than 8-wave ones: the vision tower's 1025 rows are 9 x 4 instead of 5 x 8 with seven
+    // waves of the last workgroup idle (3.5 % faster on one box; 3-wave workgroups, 11 x 3 with no idle wave at all,
+    // measured 7 % slower: more staging per row).
+    int dense_waves = 8;
+    if (dense) {
+        if (causal && k_rows_total < q_rows_total) return fail(LV_EINVAL, "lvattn_fwd_dense: causal needs k_rows >= q_rows (%d < %d)", k_rows_total, q_rows_total);
+        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d);
+        if (lockstep) {
+            auto slots = [&](int nw) { return (q_rows_total + 32 * nw - 1) / (32 * nw) * nw; };
+            if (fwd_waves() == 4 || slots(4) < slots(8)) dense_waves = 4;
+        }
+        n_blocks = (q_rows_total + dense_waves * 32 - 1) / (dense_waves * 32);
+        desc_dev = nullptr;
+    }
     if (n_blocks == 0) return LV_OK;
     if ((int64_t)n_blocks * hq > 0x7fffffffLL) return fail(LV_EINVAL, "grid too large");
     FwdParams p{};
@@ -227,7 +248,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
     }
     const int rc = fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
                    : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
-                                     : lv_launch_fwd(p, d, causal, fwd_waves(), (hipStream_t)stream);
+                                     : lv_launch_fwd(p, d, causal, dense ? dense_waves : fwd_waves(), (hipStream_t)stream);
     if (rc) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }
@@ -239,6 +260,14 @@ extern "C" int lvattn_fwd(const void* q, const void* k, const void* v, void* out
                           int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream) {
     return fwd_impl(q, k, v, out, lse, desc_dev, n_blocks, q_rows_total, k_rows_total, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs,
                     o_rs, o_hs, lse_stride, scale, causal, stream, nullptr);
+}
+
+extern "C" int lvattn_fwd_dense(const void* q, const void* k, const void* v, void* out, float* lse,
+                                int q_rows, int k_rows, int hq, int hkv, int d,
+                                int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                                int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream) {
+    return fwd_impl(q, k, v, out, lse, nullptr, 0, q_rows, k_rows, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs,
+                    o_rs, o_hs, lse_stride, scale, causal, stream, nullptr, true);
 }
 
 extern "C" int lvattn_fwd_rope(const void* q, const void* k, const void* v, void* out, float* lse,

@@ -29,6 +29,23 @@ struct FwdParams {
 // the head's K / V then come into that L2 once instead of once per XCD that hosts one of its items (the vision
 // tower: 1024 heads x 4-5 query blocks, where the plain order fetched K / V four times, L2 hit rate 41 %).
 inline bool lv_head_per_xcd(const FwdParams& p) { return (int64_t)p.n_blocks * p.group <= 32 && p.hkv >= 8; }
+#ifdef __HIPCC__
+// Work item `blk` of a forward launch: the caller's descriptor, or (desc == nullptr: ONE dense segment, no descriptor
+// memory at all) rows [blk * bm, + bm) of q_rows_total query rows against all k_rows_total keys; the causal rule is
+// aligned to the END of both ranges (query row i sees keys j <= i + k_rows_total - q_rows_total).  Causal blocks are
+// numbered from the last one down: heaviest first, as the host block builders order theirs.
+__device__ __forceinline__ AttnDesc lv_fwd_desc(const FwdParams& p, int blk, int bm, bool causal) {
+    if (p.desc) return p.desc[blk];
+    if (causal) blk = p.n_blocks - 1 - blk;
+    AttnDesc d;
+    d.a_row0 = blk * bm;
+    d.a_rows = min(bm, p.q_rows_total - d.a_row0);
+    d.b_row0 = 0;
+    d.shift = causal ? p.k_rows_total - p.q_rows_total + d.a_row0 : 0;
+    d.b_len = causal ? max(0, min(p.k_rows_total, d.a_rows + d.shift)) : p.k_rows_total;
+    return d;
+}
+#endif
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
 int lv_launch_fwd_pp16(const FwdParams& p, int causal, hipStream_t stream);      // ping-pong form on 16x16x32 MFMAs, d = 128

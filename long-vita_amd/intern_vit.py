@@ -76,7 +76,7 @@ class InternViTTransformerLayer(torch.nn.Module):
         self.heads = cfg.num_attention_heads
         self.eps = cfg.layernorm_epsilon
 
-    def forward(self, hidden_states: torch.Tensor, desc: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         """hidden_states [s, b, h] bf16 -> [s, b, h] (intern_vit_model.py:32-89)."""
         s, b, h = hidden_states.shape
         hn = h // self.heads
@@ -89,7 +89,7 @@ class InternViTTransformerLayer(torch.nn.Module):
         if torch.is_grad_enabled() and qkv.requires_grad:
             ctx, _ = ops.varlen_attention(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], [0, s], 1.0 / math.sqrt(hn), False)
         else:
-            ctx, _ = ops.attn_fwd_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], desc, 1.0 / math.sqrt(hn), False)
+            ctx, _ = ops.attn_fwd_dense_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], 1.0 / math.sqrt(hn), False)
         proj = F.linear(ctx.reshape(s * b, h), sa.linear_proj.weight)
         x1 = ops.bias_scale_residual(proj, sa.linear_proj.bias, self.ls1, hidden_states.view(s * b, h))
         y = ops.layernorm(x1, self.pre_mlp_layernorm.weight, self.pre_mlp_layernorm.bias, self.eps)
@@ -106,8 +106,7 @@ class InternViTTransformerLayer(torch.nn.Module):
         sa, mlp = self.self_attention, self.mlp
         qkv = F.linear(normed.view(s * b, h), sa.linear_qkv.weight, sa.linear_qkv.bias)
         hv = qkv.view(s, b * self.heads, 3 * hn)
-        desc = ops.blocks_on_device([0, s], False, False, hidden_states.device)
-        ctx, _ = ops.attn_fwd_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], desc, 1.0 / math.sqrt(hn), False)
+        ctx, _ = ops.attn_fwd_dense_launch(hv[:, :, :hn], hv[:, :, hn:2 * hn], hv[:, :, 2 * hn:], 1.0 / math.sqrt(hn), False)
         proj = F.linear(ctx.reshape(s * b, h), sa.linear_proj.weight)
         x1, y = ops.bias_scale_residual_layernorm_launch(proj, sa.linear_proj.bias, self.ls1, hidden_states.view(s * b, h),
                                                          self.pre_mlp_layernorm.weight, self.pre_mlp_layernorm.bias, self.eps)
@@ -184,7 +183,6 @@ class InternViTModel(torch.nn.Module):
             for i, layer in enumerate(layers):
                 tokens, normed = layer.forward_fused(tokens, normed, layers[i + 1] if i + 1 < len(layers) else None)
             return tokens.permute(1, 0, 2).contiguous()
-        desc = ops.blocks_on_device([0, self.seq_length], False, False, x.device)
         for layer in layers:
-            tokens = layer(tokens, desc)
+            tokens = layer(tokens)
         return tokens.permute(1, 0, 2).contiguous()

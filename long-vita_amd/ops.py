@@ -164,6 +164,25 @@ def attn_fwd_launch(q, k, v, desc: torch.Tensor, scale: float, causal: bool, out
     return out, lse
 
 
+def attn_fwd_dense_launch(q, k, v, scale: float, causal: bool, out=None, lse=None):
+    """attn_fwd_launch for ONE dense segment (all of q's rows against all of k's, every head) without descriptors:
+    the library numbers the work items itself and sizes its workgroups to the row count (lvattn_fwd_dense).  What the
+    vision tower's attention (dot_product_attention.py:314-325) runs through."""
+    q, k, v = _last_contig(q), _last_contig(k), _last_contig(v)
+    _check_qkv(q, k, v)
+    rq, hq, d = q.shape
+    rk, hkv, _ = k.shape
+    if out is None:
+        out = torch.empty((rq, hq, d), dtype=torch.bfloat16, device=q.device)
+    if lse is None:
+        lse = torch.empty((hq, rq), dtype=torch.float32, device=q.device)
+    check(_lib.lib().lvattn_fwd_dense(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), rq, rk, hq, hkv, d,
+        q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+        out.stride(0), out.stride(1), lse.stride(0), float(scale), int(causal), _stream()), "lvattn_fwd_dense")
+    return out, lse
+
+
 def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, n_split: int = 0, return_lse: bool = False,
                      out: torch.Tensor | None = None, lse: torch.Tensor | None = None, library_scratch: bool = False):
     """One new token per sequence against a KV cache: q [b, hq, d], k / v [b, k_len, hkv, d] bf16 (any batch / row /
@@ -256,12 +275,15 @@ def merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0: int, rows: int, init:
 class _VarlenAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu_seqlens, scale, causal):
-        desc = blocks_on_device(cu_seqlens, causal, False, q.device)
         total = q.shape[0]
-        covered = len(cu_seqlens) > 1 and cu_seqlens[0] == 0 and cu_seqlens[-1] == total
-        out = None if covered else torch.zeros(q.shape, dtype=q.dtype, device=q.device)
-        lse = None if covered else torch.full((q.shape[1], total), float("-inf"), dtype=torch.float32, device=q.device)
-        out, lse = attn_fwd_launch(q, k, v, desc, scale, causal, out, lse)
+        if len(cu_seqlens) == 2 and cu_seqlens[0] == 0 and cu_seqlens[1] == total == k.shape[0]:
+            out, lse = attn_fwd_dense_launch(q, k, v, scale, causal)      # one segment over every row: no descriptors
+        else:
+            desc = blocks_on_device(cu_seqlens, causal, False, q.device)
+            covered = len(cu_seqlens) > 1 and cu_seqlens[0] == 0 and cu_seqlens[-1] == total
+            out = None if covered else torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+            lse = None if covered else torch.full((q.shape[1], total), float("-inf"), dtype=torch.float32, device=q.device)
+            out, lse = attn_fwd_launch(q, k, v, desc, scale, causal, out, lse)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.cu_seqlens = tuple(cu_seqlens)
         ctx.scale = scale

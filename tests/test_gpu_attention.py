@@ -278,6 +278,50 @@ def test_every_forward_kernel_variant(kernel):
         _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"no-such-kernel"), "select")
 
 
+@pytest.mark.parametrize("rows,k_rows,Hq,Hkv,D,causal", [
+    (1025, 1025, 32, 32, 64, False),      # the vision tower's shape: 8 x 128 rows + 1 (4-wave workgroups)
+    (1024, 1024, 16, 16, 64, False),      # no rows past the last full item (8-wave workgroups)
+    (37, 37, 4, 4, 64, False), (300, 300, 4, 2, 64, True),
+    (700, 700, 10, 2, 128, True), (130, 450, 10, 2, 128, True),   # the second: causal rule aligned to the end of a longer key range
+    (257, 513, 4, 2, 64, True), (513, 300, 5, 5, 128, False)])
+def test_dense_entry_point(rows, k_rows, Hq, Hkv, D, causal):
+    """lvattn_fwd_dense (one segment, no descriptors, workgroup size chosen from the row count) against the oracle and,
+    bit for bit, against lvattn_fwd on the descriptors of the same rectangle."""
+    from long_vita_amd import ops
+    g = torch.Generator().manual_seed(rows + k_rows + D)
+    q = (torch.randn(rows, Hq, D, generator=g) * 0.7).to(torch.bfloat16)
+    k = (torch.randn(k_rows, Hkv, D, generator=g) * 0.7).to(torch.bfloat16)
+    v = (torch.randn(k_rows, Hkv, D, generator=g) * 0.7).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    out, lse = ops.attn_fwd_dense_launch(q.cuda(), k.cuda(), v.cuda(), scale, causal)
+    desc = ops.rect_blocks_on_device(0, rows, 0, k_rows, causal, k_rows - rows, False, "cuda")
+    out2, lse2 = ops.attn_fwd_launch(q.cuda(), k.cuda(), v.cuda(), desc, scale, causal)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    if rows == k_rows:
+        ref_o, ref_lse = A.varlen_attention(q, k, v, [0, rows], scale, causal)
+        assert rel_err(out, ref_o) <= REL_TOL
+        assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL
+
+
+def test_dense_entry_point_strided_views_and_errors():
+    """The tower's layout: q, k, v as strided views of one [s, b * heads, 3 * d] GEMM output; bad calls fail loudly."""
+    from long_vita_amd import ops, _lib
+    s, heads, d = 1025, 24, 64
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(s, heads, 3 * d, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+    out, lse = ops.attn_fwd_dense_launch(q, k, v, A.default_scale(d), False)
+    ref_o, ref_lse = A.varlen_attention(q.cpu().contiguous(), k.cpu().contiguous(), v.cpu().contiguous(), [0, s], A.default_scale(d), False)
+    torch.cuda.synchronize()
+    assert rel_err(out, ref_o) <= REL_TOL
+    assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL
+    with pytest.raises(_lib.LvAttnError, match="k_rows >= q_rows"):
+        ops.attn_fwd_dense_launch(q, k[:100], v[:100], 0.125, True)
+    with pytest.raises(_lib.LvAttnError):
+        ops.attn_fwd_dense_launch(q[:, :, :32], k[:, :, :32], v[:, :, :32], 0.125, False)     # head dim 32
+
+
 def test_full_size_backward_invariants_cfg3():
     """Backward at the 131,072-token / 40-8-head size of the forward+backward measurements, checked through identities
     that hold at any size: rows of P sum to one, so  sum_j dV[j] = sum over the group's heads and all rows of dO;

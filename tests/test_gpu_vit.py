@@ -104,9 +104,8 @@ def test_layer_and_model_against_reference_fixture(golden_dir):
     m = _model(dict(hidden_size=h, ffn_hidden_size=ffn, num_attention_heads=heads, num_layers=n_layers, patch_dim=patch,
                     img_h=img_hw, img_w=img_hw, layernorm_epsilon=float(g["eps"])), sd)
     x = torch.from_numpy(g["layer0.in"]).to(torch.bfloat16).cuda()
-    desc = ops.blocks_on_device([0, x.shape[0]], False, False, x.device)
     with torch.no_grad():
-        y = m.decoder.layers[0](x, desc)
+        y = m.decoder.layers[0](x)
     _close(y, torch.from_numpy(g["layer0.out"]))
     out = m(torch.from_numpy(g["model.img"]).to(torch.bfloat16).cuda())
     _close(out, torch.from_numpy(g["model.out"]))
@@ -394,7 +393,6 @@ def test_frozen_tower_fused_loop_equals_layer_by_layer():
         patches = ops.patchify(img, cfg.patch_dim, m._patch_weight().shape[1])
         proj = torch.matmul(patches, m._patch_weight().t()).view(2, m.num_patches, cfg.hidden_size)
         tokens = ops.embed_tokens(proj, m.conv1.bias, m.class_token, m.position_embeddings.weight)
-        desc = ops.blocks_on_device([0, m.seq_length], False, False, img.device)
         for layer in m.decoder.layers:
-            tokens = layer(tokens, desc)
+            tokens = layer(tokens)
     assert torch.equal(fused, tokens.permute(1, 0, 2).contiguous())
