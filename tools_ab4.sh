@@ -6,7 +6,7 @@ cp $L /tmp/lv_orig.so
 for r in $(seq $ROUNDS); do
   for v in $VARS; do
     IFS=: read lib units <<< "$v"
-    cp long-vita_amd/$lib $L
+    [ "$lib" = liblvattn.so ] && cp /tmp/lv_orig.so $L || cp long-vita_amd/$lib $L
     LVATTN_DKDV_UNITS=$units timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), round(d['roofline']['achieved'],1))" || { cp /tmp/lv_orig.so $L; exit 1; }
   done
 done
