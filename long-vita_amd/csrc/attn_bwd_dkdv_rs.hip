@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 #define LV_RS_MAP 1   // key block -> workgroup order: 0 = KV-head-major, 1 = KV head fastest (one head group per XCD)
 #endif
 #ifndef LV_RS_CFOLD
-#define LV_RS_CFOLD 1   // row constants ride in as the C operand of the S / dP products (see the kernel)
+#define LV_RS_CFOLD 0   // 1: row constants ride in as the C operand of the S / dP products (see the kernel); measured equal, off
 #endif
 #ifndef LV_RS_DEPTH1
 #define LV_RS_DEPTH1 2   // one unit per iteration: how many iterations ahead the staging requests run
