@@ -118,6 +118,16 @@ def test_argument_validation_rejects_before_any_launch():
     assert rc != 0 and "lse_stride" in err()
     # zero work items: accepted, nothing launched
     assert L.lvattn_fwd(p, p, p, p, p, p, 0, 64, 64, 4, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None) == 0
+    # a row stride the kernels' 32-bit tile offsets cannot span
+    rc = L.lvattn_fwd(p, p, p, p, p, p, 1, 64, 64, 4, 2, 128, 1 << 23, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None)
+    assert rc != 0 and "row stride" in err()
+    # the descriptor-free form: same checks; causal needs at least as many keys as rows
+    rc = L.lvattn_fwd_dense(p, p, p, p, p, 64, 64, 4, 2, 96, 1024, 96, 512, 96, 512, 96, 1024, 96, 64, f, 0, None)
+    assert rc != 0 and "head dim" in err()
+    rc = L.lvattn_fwd_dense(p, p, p, p, p, 64, 32, 4, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None)
+    assert rc != 0 and "k_rows >= q_rows" in err()
+    rc = L.lvattn_fwd_dense(p, p, p, p, None, 64, 64, 4, 2, 128, 1024, 128, 512, 128, 512, 128, 1024, 128, 64, f, 1, None)
+    assert rc != 0 and "null" in err()
     # incremental attention: 33 query heads per KV head, empty cache, short workspace
     ws = L.lvattn_decode_workspace_bytes(1, 40, 8, 128)
     assert ws > 0 and L.lvattn_decode_workspace_bytes(1, 5, 2, 128) == 0
