@@ -29,7 +29,7 @@ extern "C" int lvattn_abi_version(void) { return 1; }
 // LVATTN_FWD_KERNEL=pp / lockstep forces one of them for every head dim.
 static int fwd_kernel_code(const char* e) {   // 0 default, 1 ping-pong (32x32x16 MFMAs), 2 lockstep, 3 ping-pong on 16x16x32 MFMAs
     if (!e) return 0;
-    return !strcmp(e, "pp") ? 1 : (!strcmp(e, "lockstep") ? 2 : (!strcmp(e, "pp16") ? 3 : 0));
+    return !strcmp(e, "pp") ? 1 : (!strcmp(e, "lockstep") ? 2 : (!strcmp(e, "pp16") ? 3 : (!strcmp(e, "a4") ? 4 : 0)));
 }
 static int g_fwd_kernel = -1;   // -1: not read yet
 static int fwd_kernel_override() {
@@ -37,7 +37,7 @@ static int fwd_kernel_override() {
     return g_fwd_kernel;
 }
 extern "C" int lvattn_select_fwd_kernel(const char* name) {
-    if (name && name[0] && strcmp(name, "default") && !fwd_kernel_code(name)) return fail(LV_EINVAL, "unknown forward kernel '%s' (default, pp, pp16, lockstep)", name);
+    if (name && name[0] && strcmp(name, "default") && !fwd_kernel_code(name)) return fail(LV_EINVAL, "unknown forward kernel '%s' (default, pp, pp16, a4, lockstep)", name);
     g_fwd_kernel = fwd_kernel_code(name);
     return LV_OK;
 }
@@ -57,6 +57,7 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
     return LV_OK;
 }
 static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
+static bool fwd_a4(int d) { return d == 128 && fwd_kernel_override() == 4; }
 static bool fwd_pingpong(int d) {
     const int o = fwd_kernel_override();
     return o == 1 || (o == 0 && d == 128);
@@ -211,7 +212,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
     int dense_waves = 8;
     if (dense) {
         if (causal && k_rows_total < q_rows_total) return fail(LV_EINVAL, "lvattn_fwd_dense: causal needs k_rows >= q_rows (%d < %d)", k_rows_total, q_rows_total);
-        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d);
+        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d);
         if (lockstep) {
             auto slots = [&](int nw) { return (q_rows_total + 32 * nw - 1) / (32 * nw) * nw; };
             if (fwd_waves() == 4 || slots(4) < slots(8)) dense_waves = 4;
@@ -246,7 +247,8 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
         if (lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
         return LV_OK;
     }
-    const int rc = fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
+    const int rc = fwd_a4(d) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
+                   : fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
                    : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
                                      : lv_launch_fwd(p, d, causal, dense ? dense_waves : fwd_waves(), (hipStream_t)stream);
     if (rc) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));

@@ -49,6 +49,7 @@ __device__ __forceinline__ AttnDesc lv_fwd_desc(const FwdParams& p, int blk, int
 int lv_launch_fwd(const FwdParams& p, int d, int causal, int waves, hipStream_t stream);
 int lv_launch_fwd_pp(const FwdParams& p, int d, int causal, hipStream_t stream);  // ping-pong form, 256-row items
 int lv_launch_fwd_pp16(const FwdParams& p, int causal, hipStream_t stream);      // ping-pong form on 16x16x32 MFMAs, d = 128
+int lv_launch_fwd_a4(const FwdParams& p, int causal, hipStream_t stream);        // one wave per SIMD, 64 query rows per wave, d = 128
 
 // Incremental attention over a KV cache: q [batch, hq, d], k/v [batch, k_len, hkv, d], out [batch, hq, d].
 #define LV_DECODE_MAX_SPLITS 256
