@@ -13,8 +13,11 @@
 // The accumulator registers are named as clobbers once so that the kernel descriptor allocates them; the build must
 // show no compiler v_accvgpr_* and no spill (the vector half has to stay within 256 registers).
 //
-// K / V tiles live in a 3-slot LDS ring (slot t % 3 = [K tile t][V tile t]), requested two tiles ahead by direct
-// global -> LDS loads (each wave a quarter of each), a counted s_waitcnt vmcnt before the tile's barrier.
+// The loop is software-pipelined: iteration t holds O^T += V_{t-1}^T P_{t-1}^T, S_{t+1}^T = K_{t+1} Q^T and the softmax of
+// S_t, the vector work spread over the 64 MFMA gaps of the iteration; one workgroup barrier per 64-key tile.
+// K / V tiles live in a 3-slot LDS ring (slot i % 3 = [K tile i][V tile i]); iteration t requests K tile t+3 and V tile
+// t+1 by direct global -> LDS loads (each wave a quarter of each), a counted s_waitcnt vmcnt before the barrier leaves
+// the newest iteration's requests in flight.
 #include "internal.h"
 #include <type_traits>
 
@@ -94,8 +97,23 @@ template <int OA>
 __device__ __forceinline__ void a4_mfma_o(bf16x8 vf, bf16x8 pf) {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf), "v"(pf), "i"(OA), "i"(OA + 15));
 }
+// two fp32 -> one dword of two bf16 (round to nearest even), the first in the low half
+__device__ __forceinline__ uint32_t a4_pack(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    bf16x2_ v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
 template <int N>
 __device__ __forceinline__ void a4_nop() { asm volatile("s_nop %c0" :: "i"(N - 1)); }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void a4_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        a4_static_for<I + 1, N>(f);
+    }
+}
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
@@ -191,8 +209,8 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         const int row = prow0 + RPP * j;
         row_ch[j] = (row << 8) | (lds_off128(row, lane % CPR) - row * ROWB);
     }
-    // one tile: K (isv = 0) or V (isv = 1) rows of tile t into its ring slot
-    auto issue_tile = [&](int t, int isv) __attribute__((always_inline)) {
+    // piece j of K tile t (isv = 0) or V tile t (isv = 1) into its ring slot
+    auto issue_piece = [&](int t, int isv, int j) __attribute__((always_inline)) {
         int rows = rows_avail - t * BN;
         rows = rows < 0 ? 0 : (rows > BN ? BN : rows);
         const int64_t rs_ = isv ? p.v_rs : p.k_rs;
@@ -205,12 +223,9 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         const char* ubase = (const char*)(uintptr_t)(((uint64_t)b_hi << 32) | (uint64_t)b_lo);
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)rec), 0x00020000);
         const int last = rows - 1;
-        const uint32_t dst = lds_base + (uint32_t)((t % NS) * SLOTB + (isv ? TILEB : 0) + PPW * w * 1024);
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int row = min(row_ch[j] >> 8, last < 0 ? 0 : last);   // rows past the end repeat the last valid one
-            a4_dma16(rsrc, row * (int)(rs_ * 2) + (row_ch[j] & 255), dst + j * 1024);
-        }
+        const uint32_t dst = lds_base + (uint32_t)((t % NS) * SLOTB + (isv ? TILEB : 0) + (PPW * w + j) * 1024);
+        const int row = min(row_ch[j] >> 8, last < 0 ? 0 : last);   // rows past the end repeat the last valid one
+        a4_dma16(rsrc, row * (int)(rs_ * 2) + (row_ch[j] & 255), dst);
     };
 
     // ---- LDS read addresses in slot 0
@@ -227,116 +242,175 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
 
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
     const float cs = p.scale_log2e;
+    f32x16 sA[2][2], sB[2][2];        // S^T of two consecutive tiles: [column block][32-key half]
+    a4_u32x4 pA[2][2][2], pB[2][2][2];  // P^T (bf16 pairs) of two consecutive tiles: [column block][half][16-key quarter]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pA[c][st][s2][i] = 0u; pB[c][st][s2][i] = 0u; }
 
-    if (nkt > 0) {
-        issue_tile(0, 0); issue_tile(0, 1);
-        issue_tile(1, 0); issue_tile(1, 1);
-        for (int t = 0; t < nkt; ++t) {
-            // tile t has landed (the newest requests, tile t + 1's, may still be in flight); every wave is past tile t - 1
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            issue_tile(t + 2, 0); issue_tile(t + 2, 1);     // into the slot tile t - 1 has left
-            const int sb = (t % NS) * SLOTB;
-            if (t < my_nkt) {
-                // ---- K fragments -> a[192:255]
-#define A4_RK(st, ks) a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_addr[ks] + sb);
-                A4_RK(0, 0) A4_RK(0, 1) A4_RK(0, 2) A4_RK(0, 3) A4_RK(0, 4) A4_RK(0, 5) A4_RK(0, 6) A4_RK(0, 7)
-                A4_RK(1, 0) A4_RK(1, 1) A4_RK(1, 2) A4_RK(1, 3) A4_RK(1, 4) A4_RK(1, 5) A4_RK(1, 6) A4_RK(1, 7)
-#undef A4_RK
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // ---- S^T = K Q^T : s[c][st]
-                f32x16 s[2][2];
-#define A4_S(c, st, ks, first) a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), first>(s[c][st]);
-#define A4_S8(c, st) A4_S(c, st, 0, true) A4_S(c, st, 1, false) A4_S(c, st, 2, false) A4_S(c, st, 3, false) \
-                     A4_S(c, st, 4, false) A4_S(c, st, 5, false) A4_S(c, st, 6, false) A4_S(c, st, 7, false)
-                A4_S8(0, 0) A4_S8(1, 0) A4_S8(0, 1) A4_S8(1, 1)
-#undef A4_S8
-#undef A4_S
-                a4_nop<12>();     // MFMA result -> vector reader
-                asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));
-                // ---- softmax -> P^T (bf16)
-                bf16x8 pf[2][2][2];
-                const int kb0 = t * BN;
-                const bool need_mask = (kb0 + BN - 1 > 64 * w + shift) || (kb0 + BN > k_len);
-                bool exact = need_mask || __any(m_run[0] < -1e29f || m_run[1] < -1e29f);
-                if (!exact) {
-                    float rs[2] = {0.f, 0.f};
+    // exact softmax of tile t held in sc (mask, row maximum, deferred rescale) -> pf; updates m_run / l_run / O
+    auto softmax_exact = [&](f32x16 (&sc)[2][2], a4_u32x4 (&pf)[2][2][2], int t, bool need_mask) __attribute__((always_inline)) {
+        const int kb0 = t * BN;
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const float mc = m_run[c] * cs;
+        for (int c = 0; c < 2; ++c) {
+            if (need_mask) {
 #pragma unroll
-                        for (int st = 0; st < 2; ++st)
+                for (int st = 0; st < 2; ++st)
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                float pv = fast_exp2(__builtin_fmaf(s[c][st][i], cs, -mc));
-                                rs[c] += pv;
-                                pf[c][st][i >> 3][i & 7] = (__bf16)pv;
-                            }
+                    for (int i = 0; i < 16; ++i) {
+                        int j = kb0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        sc[c][st][i] = (j > limit[c]) ? -INFINITY : sc[c][st][i];
                     }
-                    if (__any(!(rs[0] <= OPTIMISTIC_MAX) || !(rs[1] <= OPTIMISTIC_MAX))) exact = true;
-                    else { l_run[0] += rs[0]; l_run[1] += rs[1]; }
+            }
+            float mx = sc[c][0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc[c][0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[c][1][i]);
+            mx = pair32_max(mx);
+            const float m_new = fmaxf(m_run[c], mx);
+            const bool grow = (m_new - m_run[c]) * cs > RESCALE_LOG2;
+            if (__any(grow)) {
+                const float alpha = fast_exp2((m_run[c] - m_new) * cs);
+                m_run[c] = m_new;
+                l_run[c] *= alpha;
+                if (c == 0) a4_scale<0, 64>(alpha); else a4_scale<64, 64>(alpha);
+            }
+            const float mc = m_run[c] * cs;
+            float rs = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const float pa = fast_exp2(__builtin_fmaf(sc[c][st][i], cs, -mc));
+                    const float pb = fast_exp2(__builtin_fmaf(sc[c][st][i + 1], cs, -mc));
+                    rs += pa + pb;
+                    pf[c][st][i >> 3][(i & 7) >> 1] = a4_pack(pa, pb);
                 }
-                if (exact) {
+            l_run[c] += rs;
+        }
+    };
+
+    // One iteration (one barrier): 64 MFMAs, each followed by its share of the other work ("gap" k = 0 .. 63):
+    //   gaps  0-31  O^T += V_{t-1}^T P_{t-1}^T   group g = k / 8 = (st, s2), then (mt, c)
+    //   gaps 32-63  S_{t+1}^T = K_{t+1} Q^T       segment (st, kh), then (ks, c)
+    //   every gap   softmax of S_t -> P_t against the running maximum (optimistic pass): even gaps the two exponentials
+    //               of a pair of scores, odd gaps the row sums and the cast; a tile that needs masking or whose sums
+    //               come out too large is redone exactly after the gaps (S_t is still intact)
+    //   gaps  0-23  V fragments of the next group;  gaps 16-31  K_{t+1} fragments -> a[192:255];  8 staging requests
+    auto iteration = [&](int t, f32x16 (&scur)[2][2], f32x16 (&snext)[2][2], a4_u32x4 (&pprev)[2][2][2], a4_u32x4 (&pcur)[2][2][2])
+                         __attribute__((always_inline)) {
+        // everything older than the previous iteration's requests has landed (K tile t+1, V tile t-1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int vb = ((t + NS - 1) % NS) * SLOTB;     // slot of V tile t-1 (t = 0: P is zero, whatever is read)
+        const uint32_t kb = (uint32_t)(((t + 1) % NS) * SLOTB);   // slot of K tile t+1
+        const bool active = (t < my_nkt);
+        const int kb0 = t * BN;
+        const bool need_mask = (kb0 + BN - 1 > 64 * w + shift) || (kb0 + BN > k_len);
+        const bool fast = active && !need_mask && !__any(m_run[0] < -1e29f || m_run[1] < -1e29f);
+        const float mc0 = m_run[0] * cs, mc1 = m_run[1] * cs;
+        float rs0 = 0.f, rs1 = 0.f;
+        float pvA = 0.f, pvB = 0.f;
+        bf16x8 vfr[2][MT];
+        auto load_v = [&](int set, int g) __attribute__((always_inline)) {
+            const int voff = vb + (32 * (g >> 1) + 16 * (g & 1)) * ROWB;
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        if (need_mask) {
-#pragma unroll
-                            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                                for (int i = 0; i < 16; ++i) {
-                                    int j = kb0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * h;
-                                    s[c][st][i] = (j > limit[c]) ? -INFINITY : s[c][st][i];
-                                }
-                        }
-                        float mx = s[c][0][0];
-#pragma unroll
-                        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[c][0][i]);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[c][1][i]);
-                        mx = pair32_max(mx);
-                        const float m_new = fmaxf(m_run[c], mx);
-                        const bool grow = (m_new - m_run[c]) * cs > RESCALE_LOG2;
-                        if (__any(grow)) {
-                            const float alpha = fast_exp2((m_run[c] - m_new) * cs);
-                            m_run[c] = m_new;
-                            l_run[c] *= alpha;
-                            if (c == 0) a4_scale<0, 64>(alpha); else a4_scale<64, 64>(alpha);
-                        }
-                        const float mc = m_run[c] * cs;
-                        float rs = 0.f;
-#pragma unroll
-                        for (int st = 0; st < 2; ++st)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                float pv = fast_exp2(__builtin_fmaf(s[c][st][i], cs, -mc));
-                                rs += pv;
-                                pf[c][st][i >> 3][i & 7] = (__bf16)pv;
-                            }
-                        l_run[c] += rs;
-                    }
-                }
-                // ---- O^T += V^T P^T
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int st = g >> 1, s2 = g & 1;
-                    const int voff = sb + (32 * st + 16 * s2) * ROWB;
-                    bf16x8 vf[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][0] + voff));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][1] + voff));
-                        vf[mt][0] = lo[0]; vf[mt][1] = lo[1]; vf[mt][2] = lo[2]; vf[mt][3] = lo[3];
-                        vf[mt][4] = hi[0]; vf[mt][5] = hi[1]; vf[mt][6] = hi[2]; vf[mt][7] = hi[3];
-                    }
-                    // the fragments and P were written by vector instructions: two wait states before an MFMA reads them
-                    asm volatile("s_nop 1" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(pf[0][st][s2]), "+v"(pf[1][st][s2]));
-                    a4_mfma_o<a4_O(0, 0)>(vf[0], pf[0][st][s2]); a4_mfma_o<a4_O(1, 0)>(vf[0], pf[1][st][s2]);
-                    a4_mfma_o<a4_O(0, 1)>(vf[1], pf[0][st][s2]); a4_mfma_o<a4_O(1, 1)>(vf[1], pf[1][st][s2]);
-                    a4_mfma_o<a4_O(0, 2)>(vf[2], pf[0][st][s2]); a4_mfma_o<a4_O(1, 2)>(vf[2], pf[1][st][s2]);
-                    a4_mfma_o<a4_O(0, 3)>(vf[3], pf[0][st][s2]); a4_mfma_o<a4_O(1, 3)>(vf[3], pf[1][st][s2]);
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][0] + voff));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][1] + voff));
+                bf16x8& vf = vfr[set][mt];
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            }
+        };
+        load_v(0, 0);
+        a4_static_for<0, 64>([&](auto K_) __attribute__((always_inline)) {
+            constexpr int k = decltype(K_)::value;
+            // ---- the MFMA of this gap
+            if constexpr (k < 32) {
+                constexpr int g = k >> 3, st = g >> 1, s2 = g & 1, mt = (k & 7) >> 1, c = k & 1;
+                if constexpr ((k & 7) == 0 && g < 3) load_v((g + 1) & 1, g + 1);      // the next group's fragments
+                a4_mfma_o<a4_O(c, mt)>(vfr[g & 1][mt], __builtin_bit_cast(bf16x8, pprev[c][st][s2]));
+            } else {
+                constexpr int sg = (k - 32) >> 3, st = sg >> 1, kh = sg & 1, ks = 4 * kh + ((k & 7) >> 1), c = k & 1;
+                if constexpr (k == 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K_{t+1} fragments are in
+                a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), ks == 0>(snext[c][st]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its gap's fillers behind it
+            // ---- K_{t+1} fragments, one per gap
+            if constexpr (k >= 16 && k < 32) {
+                constexpr int f = k - 16, st = f >> 3, ks = f & 7;
+                a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_addr[ks] + kb);
+            }
+            // ---- staging requests: K tile t+3 (pieces 0-3), V tile t+1 (pieces 0-3)
+            if constexpr ((k & 7) == 5) {
+                constexpr int j = k >> 3;
+                if constexpr (j < 4) issue_piece(t + 3, 0, j); else issue_piece(t + 1, 1, j - 4);
+            }
+            // ---- softmax share: pair e of the 32 (two scores of S_t per lane)
+            {
+                constexpr int e = k >> 1, c = e >> 4, st = (e >> 3) & 1, i0 = 2 * (e & 7);
+                if constexpr ((k & 1) == 0) {
+                    pvA = fast_exp2(__builtin_fmaf(scur[c][st][i0], cs, c ? -mc1 : -mc0));
+                    pvB = fast_exp2(__builtin_fmaf(scur[c][st][i0 + 1], cs, c ? -mc1 : -mc0));
+                } else {
+                    // (the empty asm statements keep the sums and the cast in THIS gap: left alone, the compiler gathers
+                    // them at the end of the iteration and keeps all 64 exponentials alive until then)
+                    if constexpr (c) { rs1 += pvA; rs1 += pvB; asm volatile("" : "+v"(rs1)); }
+                    else { rs0 += pvA; rs0 += pvB; asm volatile("" : "+v"(rs0)); }
+                    uint32_t pw = a4_pack(pvA, pvB);
+                    asm volatile("" : "+v"(pw));
+                    pcur[c][st][i0 >> 3][(i0 & 7) >> 1] = pw;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        });
+        bool exact = active && !fast;
+        if (fast) {
+            if (__any(!(rs0 <= OPTIMISTIC_MAX) || !(rs1 <= OPTIMISTIC_MAX))) exact = true;
+            else { l_run[0] += rs0; l_run[1] += rs1; }
+        }
+        if (exact) softmax_exact(scur, pcur, t, need_mask);
+        if (!active) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pcur[c][st][s2][i] = 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nkt > 0) {
+        // prologue: K tiles 0, 1, 2 and V tile 0, then S_0
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) { issue_piece(0, 0, j); issue_piece(1, 0, j); issue_piece(2, 0, j); issue_piece(0, 1, j); }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define A4_RK(st, ks) a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_addr[ks]);
+        A4_RK(0, 0) A4_RK(0, 1) A4_RK(0, 2) A4_RK(0, 3) A4_RK(0, 4) A4_RK(0, 5) A4_RK(0, 6) A4_RK(0, 7)
+        A4_RK(1, 0) A4_RK(1, 1) A4_RK(1, 2) A4_RK(1, 3) A4_RK(1, 4) A4_RK(1, 5) A4_RK(1, 6) A4_RK(1, 7)
+#undef A4_RK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define A4_S(c, st, ks, first) a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), first>(sA[c][st]);
+#define A4_S8(c, st) A4_S(c, st, 0, true) A4_S(c, st, 1, false) A4_S(c, st, 2, false) A4_S(c, st, 3, false) \
+                     A4_S(c, st, 4, false) A4_S(c, st, 5, false) A4_S(c, st, 6, false) A4_S(c, st, 7, false)
+        A4_S8(0, 0) A4_S8(1, 0) A4_S8(0, 1) A4_S8(1, 1)
+#undef A4_S8
+#undef A4_S
+        a4_nop<12>();
+        // iteration t: PV of tile t-1, S of tile t+1, softmax of tile t; one more iteration for the last PV
+        for (int t = 0; t <= nkt; t += 2) {
+            iteration(t, sA, sB, pB, pA);
+            if (t + 1 <= nkt) iteration(t + 1, sB, sA, pA, pB);
         }
         // no staging request may outlive the workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
