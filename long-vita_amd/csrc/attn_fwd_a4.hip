@@ -10,43 +10,25 @@
 // (one per column block): half the LDS read bytes per MFMA of the 8-wave kernels, and no partner wave or second
 // barrier per tile.  The compiler neither counts nor pads what is inside an asm statement: the waits and the wait
 // states (a vector write -> MFMA operand: 2; an MFMA result -> any other reader: 12) are written out here.
-// The accumulator registers are named as clobbers once so that the kernel descriptor allocates them; the build must
-// show no compiler v_accvgpr_* and no spill (the vector half has to stay within 256 registers).
+// The build must show no compiler v_accvgpr_* and no spill (the vector half has to stay within 256 registers); see
+// the top of the kernel for how the accumulator half is kept out of the register allocator's hands.
 //
 // The loop is software-pipelined: iteration t holds O^T += V_{t-1}^T P_{t-1}^T, S_{t+1}^T = K_{t+1} Q^T and the softmax of
 // S_t, the vector work spread over the 64 MFMA gaps of the iteration; one workgroup barrier per 64-key tile.
-// K / V tiles live in a 3-slot LDS ring (slot i % 3 = [K tile i][V tile i]); iteration t requests K tile t+3 and V tile
-// t+1 by direct global -> LDS loads (each wave a quarter of each), a counted s_waitcnt vmcnt before the barrier leaves
-// the newest iteration's requests in flight.
+// K tiles live in a 4-slot LDS ring, V tiles in a 3-slot one; iteration t requests K tile t+4 and V tile t+1 by direct
+// global -> LDS loads (each wave a quarter of each), a counted s_waitcnt vmcnt before the barrier leaves the newest
+// iteration's requests in flight.  K runs further ahead because its fragments move into the accumulator registers one
+// iteration before the S product that reads them.
 #include "internal.h"
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((ext_vector_type(4))) uint32_t a4_u32x4;
 
-#define A4_CLOBBER_ALL                                                                                                  \
-    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18",  \
-        "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",  \
-        "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52",  \
-        "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69",  \
-        "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86",  \
-        "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102",     \
-        "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", \
-        "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", \
-        "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", \
-        "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", \
-        "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", \
-        "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", \
-        "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
-        "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", \
-        "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", \
-        "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", \
-        "a253", "a254", "a255"
-
-__device__ __forceinline__ void a4_dma16(__amdgpu_buffer_rsrc_t rs, int voff, uint32_t lds_dst) {
+__device__ __forceinline__ void a4_dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
 }
 
 // accumulator register numbers
@@ -124,15 +106,20 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     constexpr int ROWB = D * 2;
     constexpr int TILEB = BN * ROWB;  // 16 KiB
     constexpr int CPR = D / 8;
-    constexpr int NS = 3;
-    constexpr int SLOTB = 2 * TILEB;
+    constexpr int NKS = 4, NVS = 3;   // ring slots: K tiles t+1 .. t+4, V tiles t-1 .. t+1 around iteration t
+    constexpr int VRING = NKS * TILEB;  // byte offset of the V ring
     constexpr int RPP = 64 / CPR;     // rows per 1-KiB piece: 4
     constexpr int PPW = 4;            // pieces per wave per tile and operand
     constexpr float RESCALE_LOG2 = 8.0f;
     constexpr float OPTIMISTIC_MAX = 4096.0f;
 
-    // the accumulator half belongs to the asm statements below
-    asm volatile("" ::: A4_CLOBBER_ALL);
+    // The accumulator half belongs to the asm statements below.  Sixteen 16-register values of the accumulator class are
+    // declared here and kept alive to the end of the kernel: all 256 registers then count as occupied for the register
+    // allocator, which would otherwise park its own values in them (it does, as soon as the vector half is full).  Which
+    // value it maps to which register does not matter: it never touches them, only the asm statements do, by number.
+    f32x16 hold[16];
+    asm volatile("" : "=a"(hold[0]), "=a"(hold[1]), "=a"(hold[2]), "=a"(hold[3]), "=a"(hold[4]), "=a"(hold[5]), "=a"(hold[6]), "=a"(hold[7]),
+                      "=a"(hold[8]), "=a"(hold[9]), "=a"(hold[10]), "=a"(hold[11]), "=a"(hold[12]), "=a"(hold[13]), "=a"(hold[14]), "=a"(hold[15]));
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* const lds0 = (lds_char*)smem;
@@ -163,30 +150,30 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     const int head = kvh * p.group + hg;
 
     const AttnDesc dsc = lv_fwd_desc(p, blk, 256, CAUSAL);
-    const int q_row0 = dsc.a_row0, q_rows = dsc.a_rows;
-    const int k_row0 = dsc.b_row0, k_len = dsc.b_len;
-    const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
+    // (wave-uniform by construction; said so explicitly, or the merged dense / descriptor value sits in a vector register)
+    const int q_row0 = __builtin_amdgcn_readfirstlane(dsc.a_row0), q_rows = __builtin_amdgcn_readfirstlane(dsc.a_rows);
+    const int k_row0 = __builtin_amdgcn_readfirstlane(dsc.b_row0), k_len = __builtin_amdgcn_readfirstlane(dsc.b_len);
+    const int shift = CAUSAL ? __builtin_amdgcn_readfirstlane(dsc.shift) : 0x3fffffff;
 
     // ---- Q fragments of the two column blocks into a[128:191]: lane holds Q[row][16ks + 8h .. +8]
-    int qi[2], limit[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        qi[c] = 64 * w + 32 * c + r;
-        limit[c] = qi[c] + shift;
-        if (limit[c] > k_len - 1 || qi[c] >= q_rows) limit[c] = k_len - 1;
-    }
+    // row of column block c inside the work item, and the last key it sees (recomputed where needed: registers are short)
+    auto row_of = [&](int c) { return 64 * w + 32 * c + r; };
     {
-        a4_u32x4 qv[2][KS];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int q_row = q_row0 + (qi[c] < q_rows ? qi[c] : q_rows - 1);
+        // one column block at a time: sixteen fragments in flight together would not fit beside everything else
+        a4_u32x4 qv[KS];
+        auto load_q = [&](int c) __attribute__((always_inline)) {
+            const int q_row = q_row0 + (row_of(c) < q_rows ? row_of(c) : q_rows - 1);
             const __bf16* qptr = p.q + (int64_t)q_row * p.q_rs + (int64_t)head * p.q_hs + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qv[c][ks] = *reinterpret_cast<const a4_u32x4*>(qptr + 16 * ks);
-        }
-#define A4_PUTQ(c, ks) a4_put4<a4_Q(c, ks)>(qv[c][ks]);
+            for (int ks = 0; ks < KS; ++ks) qv[ks] = *reinterpret_cast<const a4_u32x4*>(qptr + 16 * ks);
+        };
+#define A4_PUTQ(c, ks) a4_put4<a4_Q(c, ks)>(qv[ks]);
+        load_q(0);
         A4_PUTQ(0, 0) A4_PUTQ(0, 1) A4_PUTQ(0, 2) A4_PUTQ(0, 3) A4_PUTQ(0, 4) A4_PUTQ(0, 5) A4_PUTQ(0, 6) A4_PUTQ(0, 7)
+        __builtin_amdgcn_sched_barrier(0);
+        load_q(1);
         A4_PUTQ(1, 0) A4_PUTQ(1, 1) A4_PUTQ(1, 2) A4_PUTQ(1, 3) A4_PUTQ(1, 4) A4_PUTQ(1, 5) A4_PUTQ(1, 6) A4_PUTQ(1, 7)
+        __builtin_amdgcn_sched_barrier(0);
 #undef A4_PUTQ
     }
     // O^T = 0
@@ -203,42 +190,47 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     const int64_t k_tile_bytes = (int64_t)BN * p.k_rs * 2, v_tile_bytes = (int64_t)BN * p.v_rs * 2;
     const int rows_avail = min(k_len, p.k_rows_total - k_row0);
     const int prow0 = RPP * PPW * w + lane / CPR;
-    int row_ch[PPW];   // piece j: row (bits 8..) and the swizzled 16-byte position inside the row (low bits)
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        const int row = prow0 + RPP * j;
-        row_ch[j] = (row << 8) | (lds_off128(row, lane % CPR) - row * ROWB);
-    }
-    // piece j of K tile t (isv = 0) or V tile t (isv = 1) into its ring slot
-    auto issue_piece = [&](int t, int isv, int j) __attribute__((always_inline)) {
-        int rows = rows_avail - t * BN;
-        rows = rows < 0 ? 0 : (rows > BN ? BN : rows);
+    // Piece j of a tile is rows prow0 + RPP j .. of it; since prow0 / 4 is a multiple of 4 the swizzled position of
+    // piece j differs from piece 0's by j in the chunk's low bits.  Rows past the end of the last, partial tile repeat its
+    // last valid row (a per-lane clamp, applied to every tile: two vector instructions, no branch in the loop).
+    const int ch0 = lds_off128(prow0, lane % CPR) - prow0 * ROWB;
+    struct TileSrc { __amdgpu_buffer_rsrc_t rs; int last; int stride; };
+    // what a tile's four requests share: a descriptor over its valid rows, made of scalars only
+    auto tile_src = [&](int t, int isv) __attribute__((always_inline)) {
+        int rows = __builtin_amdgcn_readfirstlane(rows_avail - t * BN);
+        rows = rows < 0 ? 0 : rows;
+        asm volatile("" : "+s"(rows));            // (two scalar steps: written as one clamp it becomes a vector med3)
+        rows = rows > BN ? BN : rows;
         const int64_t rs_ = isv ? p.v_rs : p.k_rs;
-        const uint32_t rec = rows ? (uint32_t)((rows - 1) * rs_ * 2 + ROWB) : 0u;
+        uint32_t rec = (uint32_t)(rows - 1) * (uint32_t)(rs_ * 2) + ROWB;
+        rec = rows ? rec : 0u;
         const char* base = isv ? vbase + t * v_tile_bytes : kbase + t * k_tile_bytes;
-        // (the descriptor is rebuilt from scalar halves so that it is provably wave-uniform)
         const uint64_t b64 = (uint64_t)(uintptr_t)base;
         const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32));
         const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
         const char* ubase = (const char*)(uintptr_t)(((uint64_t)b_hi << 32) | (uint64_t)b_lo);
-        auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)rec), 0x00020000);
-        const int last = rows - 1;
-        const uint32_t dst = lds_base + (uint32_t)((t % NS) * SLOTB + (isv ? TILEB : 0) + (PPW * w + j) * 1024);
-        const int row = min(row_ch[j] >> 8, last < 0 ? 0 : last);   // rows past the end repeat the last valid one
-        a4_dma16(rsrc, row * (int)(rs_ * 2) + (row_ch[j] & 255), dst);
+        TileSrc ts;
+        ts.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)rec), 0x00020000);
+        ts.last = rows > 0 ? rows - 1 : 0;
+        ts.stride = __builtin_amdgcn_readfirstlane((int)(rs_ * 2));
+        return ts;
+    };
+    auto issue_piece = [&](const TileSrc& ts, int t, int isv, int j) __attribute__((always_inline)) {
+        const uint32_t dst = lds_base + (uint32_t)((isv ? VRING + (t % NVS) * TILEB : (t % NKS) * TILEB) + (PPW * w + j) * 1024);
+        const int row = min(prow0 + RPP * j, ts.last);
+        a4_dma16(ts.rs, (int)__umul24((unsigned)row, (unsigned)ts.stride) + (ch0 ^ (j << 4)), 0, dst);
     };
 
     // ---- LDS read addresses in slot 0
-    uint32_t k_addr[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) k_addr[ks] = lds_base + (uint32_t)lds_off128(r, 2 * ks + h);
+    // The XOR swizzle acts on address bits 4..7 only and every slot starts on a multiple of 256 bytes, so the address of
+    // fragment ks (chunk 2 ks + h) is the address of fragment 0 with ks XORed into bits 5..7: one register instead of eight.
+    const uint32_t k_addr0 = lds_base + (uint32_t)lds_off128(r, h);
     const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gl = (lane >> 4) & 1;
-    lds_char* v_ptr[MT][2];
+    // likewise the d sub-tile mt (chunk 4 mt + ...) of a V read is bits 6..7
+    uint32_t v_addr0[2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh)
-            v_ptr[mt][jh] = lds0 + TILEB + lds_off128(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
+    for (int jh = 0; jh < 2; ++jh)
+        v_addr0[jh] = (uint32_t)(VRING + lds_off128(8 * jh + 4 * h + q4, 2 * gl + (p4 >> 1)) + 8 * (p4 & 1));
 
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
     const float cs = p.scale_log2e;
@@ -256,15 +248,22 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     // exact softmax of tile t held in sc (mask, row maximum, deferred rescale) -> pf; updates m_run / l_run / O
     auto softmax_exact = [&](f32x16 (&sc)[2][2], a4_u32x4 (&pf)[2][2][2], int t, bool need_mask) __attribute__((always_inline)) {
         const int kb0 = t * BN;
+        // (a rare path: the lane's row and column half come from a lane id read here, not from registers kept for it)
+        int lane_x;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_x));
+        const int r_x = lane_x & 31, h_x = lane_x >> 5;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (need_mask) {
+                const int qi_ = 64 * w + 32 * c + r_x;
+                const int lim_ = qi_ + shift;
+                const int lim = (lim_ > k_len - 1 || qi_ >= q_rows) ? k_len - 1 : lim_;
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        int j = kb0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        sc[c][st][i] = (j > limit[c]) ? -INFINITY : sc[c][st][i];
+                        int j = kb0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * h_x;
+                        sc[c][st][i] = (j > lim) ? -INFINITY : sc[c][st][i];
                     }
             }
             float mx = sc[c][0][0];
@@ -297,19 +296,21 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     };
 
     // One iteration (one barrier): 64 MFMAs, each followed by its share of the other work ("gap" k = 0 .. 63):
-    //   gaps  0-31  O^T += V_{t-1}^T P_{t-1}^T   group g = k / 8 = (st, s2), then (mt, c)
-    //   gaps 32-63  S_{t+1}^T = K_{t+1} Q^T       segment (st, kh), then (ks, c)
+    //   gaps  0-31  S_{t+1}^T = K_{t+1} Q^T       segment (st, kh), then (ks, c); the K fragments are in a[192:255] already
+    //   gaps 32-63  O^T += V_{t-1}^T P_{t-1}^T   group g = (st, s2), then (mt, c)
     //   every gap   softmax of S_t -> P_t against the running maximum (optimistic pass): even gaps the two exponentials
     //               of a pair of scores, odd gaps the row sums and the cast; a tile that needs masking or whose sums
     //               come out too large is redone exactly after the gaps (S_t is still intact)
-    //   gaps  0-23  V fragments of the next group;  gaps 16-31  K_{t+1} fragments -> a[192:255];  8 staging requests
+    //   gaps 24-55  the V fragments: group 0 before the PV half, then fragment mt of the next group behind this group's
+    //   gaps 40-55  K_{t+2} fragments -> a[192:255] (every S product of this iteration has been issued)
+    //   8 gaps      the staging requests: K tile t+4, V tile t+1
     auto iteration = [&](int t, f32x16 (&scur)[2][2], f32x16 (&snext)[2][2], a4_u32x4 (&pprev)[2][2][2], a4_u32x4 (&pcur)[2][2][2])
                          __attribute__((always_inline)) {
-        // everything older than the previous iteration's requests has landed (K tile t+1, V tile t-1)
+        // everything older than the previous iteration's requests has landed (K tile t+2, V tile t-1)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const int vb = ((t + NS - 1) % NS) * SLOTB;     // slot of V tile t-1 (t = 0: P is zero, whatever is read)
-        const uint32_t kb = (uint32_t)(((t + 1) % NS) * SLOTB);   // slot of K tile t+1
+        const int vb = ((t + NVS - 1) % NVS) * TILEB;             // slot of V tile t-1 (t = 0: P is zero, whatever is read)
+        const uint32_t kb = (uint32_t)(((t + 2) % NKS) * TILEB);  // slot of K tile t+2
         const bool active = (t < my_nkt);
         const int kb0 = t * BN;
         const bool need_mask = (kb0 + BN - 1 > 64 * w + shift) || (kb0 + BN > k_len);
@@ -317,41 +318,47 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         const float mc0 = m_run[0] * cs, mc1 = m_run[1] * cs;
         float rs0 = 0.f, rs1 = 0.f;
         float pvA = 0.f, pvB = 0.f;
-        bf16x8 vfr[2][MT];
-        auto load_v = [&](int set, int g) __attribute__((always_inline)) {
-            const int voff = vb + (32 * (g >> 1) + 16 * (g & 1)) * ROWB;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][0] + voff));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, v_ptr[mt][1] + voff));
-                bf16x8& vf = vfr[set][mt];
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-            }
-        };
-        load_v(0, 0);
+        const uint32_t k_it = k_addr0 + kb;                                  // this iteration's slot bases
+        const uint32_t v_it[2] = {v_addr0[0] + (uint32_t)vb, v_addr0[1] + (uint32_t)vb};
+        bf16x4 vh[MT][2];         // V fragments of ONE group, as the two transposed 8-byte reads of each: a fragment's
+                                  // registers are re-read for the next group as soon as its two MFMAs have been issued
+        const TileSrc src_k = tile_src(t + 4, 0), src_v = tile_src(t + 1, 1);
         a4_static_for<0, 64>([&](auto K_) __attribute__((always_inline)) {
             constexpr int k = decltype(K_)::value;
             // ---- the MFMA of this gap
             if constexpr (k < 32) {
-                constexpr int g = k >> 3, st = g >> 1, s2 = g & 1, mt = (k & 7) >> 1, c = k & 1;
-                if constexpr ((k & 7) == 0 && g < 3) load_v((g + 1) & 1, g + 1);      // the next group's fragments
-                a4_mfma_o<a4_O(c, mt)>(vfr[g & 1][mt], __builtin_bit_cast(bf16x8, pprev[c][st][s2]));
-            } else {
-                constexpr int sg = (k - 32) >> 3, st = sg >> 1, kh = sg & 1, ks = 4 * kh + ((k & 7) >> 1), c = k & 1;
-                if constexpr (k == 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // K_{t+1} fragments are in
+                constexpr int sg = k >> 3, st = sg >> 1, kh = sg & 1, ks = 4 * kh + ((k & 7) >> 1), c = k & 1;
                 a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), ks == 0>(snext[c][st]);
+            } else {
+                constexpr int g = (k - 32) >> 3, st = g >> 1, s2 = g & 1, mt = (k & 7) >> 1, c = k & 1;
+                bf16x8 vf;
+                const bf16x4 lo = vh[mt][0], hi = vh[mt][1];
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                a4_mfma_o<a4_O(c, mt)>(vf, __builtin_bit_cast(bf16x8, pprev[c][st][s2]));
             }
             __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its gap's fillers behind it
-            // ---- K_{t+1} fragments, one per gap
-            if constexpr (k >= 16 && k < 32) {
-                constexpr int f = k - 16, st = f >> 3, ks = f & 7;
-                a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_addr[ks] + kb);
+            // ---- V fragments: group 0's eight reads in gaps 24-31; in the PV half fragment mt of the NEXT group right
+            // after the second MFMA of fragment mt of this one (six gaps ahead of its first use)
+            if constexpr (k >= 24 && k < 32) {
+                constexpr int f = k - 24, mt = f >> 1, jh = f & 1;
+                vh[mt][jh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds0 + ((v_it[jh] ^ (uint32_t)(mt << 6)))));
             }
-            // ---- staging requests: K tile t+3 (pieces 0-3), V tile t+1 (pieces 0-3)
-            if constexpr ((k & 7) == 5) {
+            if constexpr (k >= 32 && k < 56 && (k & 1) == 1) {
+                constexpr int g = ((k - 32) >> 3) + 1, mt = (k & 7) >> 1;
+                constexpr int voff = (32 * (g >> 1) + 16 * (g & 1)) * ROWB;
+                vh[mt][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds0 + ((v_it[0] ^ (uint32_t)(mt << 6)) + voff)));
+                vh[mt][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds0 + ((v_it[1] ^ (uint32_t)(mt << 6)) + voff)));
+            }
+            // ---- K_{t+2} fragments, one per gap
+            if constexpr (k >= 40 && k < 56) {
+                constexpr int f = k - 40, st = f >> 3, ks = f & 7;
+                a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_it ^ (uint32_t)(ks << 5));
+            }
+            // ---- staging requests: K tile t+4 (pieces 0-3), V tile t+1 (pieces 0-3)
+            if constexpr ((k & 7) == 3) {
                 constexpr int j = k >> 3;
-                if constexpr (j < 4) issue_piece(t + 3, 0, j); else issue_piece(t + 1, 1, j - 4);
+                if constexpr (j < 4) issue_piece(src_k, t + 4, 0, j); else issue_piece(src_v, t + 1, 1, j - 4);
             }
             // ---- softmax share: pair e of the 32 (two scores of S_t per lane)
             {
@@ -371,6 +378,8 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        // the K fragments of the next iteration's S product are in (and no read of this tile's V is outstanding)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bool exact = active && !fast;
         if (fast) {
             if (__any(!(rs0 <= OPTIMISTIC_MAX) || !(rs1 <= OPTIMISTIC_MAX))) exact = true;
@@ -391,14 +400,18 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     };
 
     if (nkt > 0) {
-        // prologue: K tiles 0, 1, 2 and V tile 0, then S_0
+        // prologue: K tiles 0 .. 3 and V tile 0; S_0 from K tile 0, then the fragments of K tile 1 for iteration 0
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) { issue_piece(0, 0, j); issue_piece(1, 0, j); issue_piece(2, 0, j); issue_piece(0, 1, j); }
+        for (int j = 0; j < PPW; ++j) {
+            issue_piece(tile_src(0, 0), 0, 0, j); issue_piece(tile_src(1, 0), 1, 0, j); issue_piece(tile_src(2, 0), 2, 0, j);
+            issue_piece(tile_src(3, 0), 3, 0, j); issue_piece(tile_src(0, 1), 0, 1, j);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#define A4_RK(st, ks) a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_addr[ks]);
-        A4_RK(0, 0) A4_RK(0, 1) A4_RK(0, 2) A4_RK(0, 3) A4_RK(0, 4) A4_RK(0, 5) A4_RK(0, 6) A4_RK(0, 7)
-        A4_RK(1, 0) A4_RK(1, 1) A4_RK(1, 2) A4_RK(1, 3) A4_RK(1, 4) A4_RK(1, 5) A4_RK(1, 6) A4_RK(1, 7)
-#undef A4_RK
+#define A4_RK(st, ks, off) a4_read_k<a4_K(st, ks), st * 32 * ROWB + off>(k_addr0 ^ (uint32_t)(ks << 5));
+#define A4_RK16(off) A4_RK(0, 0, off) A4_RK(0, 1, off) A4_RK(0, 2, off) A4_RK(0, 3, off) A4_RK(0, 4, off) A4_RK(0, 5, off) A4_RK(0, 6, off) \
+                     A4_RK(0, 7, off) A4_RK(1, 0, off) A4_RK(1, 1, off) A4_RK(1, 2, off) A4_RK(1, 3, off) A4_RK(1, 4, off) A4_RK(1, 5, off) \
+                     A4_RK(1, 6, off) A4_RK(1, 7, off)
+        A4_RK16(0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define A4_S(c, st, ks, first) a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), first>(sA[c][st]);
 #define A4_S8(c, st) A4_S(c, st, 0, true) A4_S(c, st, 1, false) A4_S(c, st, 2, false) A4_S(c, st, 3, false) \
@@ -407,6 +420,10 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
 #undef A4_S8
 #undef A4_S
         a4_nop<12>();
+        A4_RK16(TILEB)
+#undef A4_RK16
+#undef A4_RK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // iteration t: PV of tile t-1, S of tile t+1, softmax of tile t; one more iteration for the last PV
         for (int t = 0; t <= nkt; t += 2) {
             iteration(t, sA, sB, pB, pA);
@@ -416,12 +433,20 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // ---- epilogue: O^T out of the accumulator half (12 wait states after the last MFMA), normalise, store
+    // ---- epilogue: O^T out of the accumulator half (12 wait states after the last MFMA), normalise, store.
+    // The lane's row is re-derived from a lane id the compiler cannot trace back, so that no output address is computed
+    // ahead of the loop and carried through it (there is no register to carry it in).
     a4_nop<12>();
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int r_e = lane_e & 31, h_e = lane_e >> 5;
+    int w_e;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(w_e) : "s"(w));   // (the same for the wave index: the scalar copy is the one to keep)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const float l_tot = pair32_sum(l_run[c]);
-        const bool live = (qi[c] < q_rows);
+        const int qi_c = 64 * w_e + 32 * c + r_e;
+        const bool live = (qi_c < q_rows);
         const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
         float o[MT][16];
 #define A4_G4(c_, mt, b) o[mt][b] = a4_get<64 * c_ + 16 * mt + b>(); o[mt][b + 1] = a4_get<64 * c_ + 16 * mt + b + 1>(); \
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
 #undef A4_G16
 #undef A4_G4
         if (live) {
-            __bf16* optr = p.o + (int64_t)(q_row0 + qi[c]) * p.o_rs + (int64_t)head * p.o_hs;
+            __bf16* optr = p.o + (int64_t)(q_row0 + qi_c) * p.o_rs + (int64_t)head * p.o_hs;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -440,14 +465,16 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                     bf16x4 ov;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = (__bf16)(o[mt][4 * g4 + e] * inv);
-                    *reinterpret_cast<bf16x4*>(optr + 32 * mt + 8 * g4 + 4 * h) = ov;
+                    *reinterpret_cast<bf16x4*>(optr + 32 * mt + 8 * g4 + 4 * h_e) = ov;
                 }
-            if (h == 0) {
+            if (h_e == 0) {
                 float lse = (l_tot > 0.f) ? (m_run[c] * p.scale + __logf(l_tot)) : -INFINITY;
-                p.lse[(int64_t)head * p.lse_stride + q_row0 + qi[c]] = lse;
+                p.lse[(int64_t)head * p.lse_stride + q_row0 + qi_c] = lse;
             }
         }
     }
+    asm volatile("" :: "a"(hold[0]), "a"(hold[1]), "a"(hold[2]), "a"(hold[3]), "a"(hold[4]), "a"(hold[5]), "a"(hold[6]), "a"(hold[7]),
+                       "a"(hold[8]), "a"(hold[9]), "a"(hold[10]), "a"(hold[11]), "a"(hold[12]), "a"(hold[13]), "a"(hold[14]), "a"(hold[15]));
 }
 
 int lv_launch_fwd_a4(const FwdParams& p0, int causal, hipStream_t stream) {
@@ -455,7 +482,7 @@ int lv_launch_fwd_a4(const FwdParams& p0, int causal, hipStream_t stream) {
     p.head_per_xcd = lv_head_per_xcd(p) ? 1 : 0;
     dim3 grid(p.head_per_xcd ? (unsigned)(((p.hkv + 7) / 8) * 8 * p.n_blocks * p.group)
                              : (unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(256);
-    size_t lds = (size_t)3 * 2 * 64 * 128 * 2;
+    size_t lds = (size_t)(4 + 3) * 64 * 128 * 2;   // K ring + V ring
     if (causal) hipLaunchKernelGGL((lv_fwd_a4_kernel<true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((lv_fwd_a4_kernel<false>), grid, block, lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
