@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         const uint32_t v_it[2] = {v_addr0[0] + (uint32_t)vb, v_addr0[1] + (uint32_t)vb};
         bf16x4 vh[MT][2];         // V fragments of ONE group, as the two transposed 8-byte reads of each: a fragment's
                                   // registers are re-read for the next group as soon as its two MFMAs have been issued
-        const TileSrc src_k = tile_src(t + 4, 0), src_v = tile_src(t + 1, 1);
+        TileSrc src_k, src_v;     // set up in gaps 0 and 2 (scalar work, behind the first MFMAs instead of ahead of them)
         a4_static_for<0, 64>([&](auto K_) __attribute__((always_inline)) {
             constexpr int k = decltype(K_)::value;
             // ---- the MFMA of this gap
@@ -355,11 +355,12 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                 constexpr int f = k - 40, st = f >> 3, ks = f & 7;
                 a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_it ^ (uint32_t)(ks << 5));
             }
-            // ---- staging requests: K tile t+4 (pieces 0-3), V tile t+1 (pieces 0-3)
-            if constexpr ((k & 7) == 3) {
-                constexpr int j = k >> 3;
-                if constexpr (j < 4) issue_piece(src_k, t + 4, 0, j); else issue_piece(src_v, t + 1, 1, j - 4);
-            }
+            // ---- staging requests: K tile t+4 (pieces 0-3), V tile t+1 (pieces 0-3), in odd gaps of the S half, where
+            // no LDS read is being issued
+            if constexpr (k == 0) src_k = tile_src(t + 4, 0);
+            if constexpr (k == 2) src_v = tile_src(t + 1, 1);
+            if constexpr (k == 5 || k == 7 || k == 11 || k == 13) issue_piece(src_k, t + 4, 0, k == 5 ? 0 : k == 7 ? 1 : k == 11 ? 2 : 3);
+            if constexpr (k == 17 || k == 19 || k == 21 || k == 23) issue_piece(src_v, t + 1, 1, (k - 17) >> 1);
             // ---- softmax share: pair e of the 32 (two scores of S_t per lane)
             {
                 constexpr int e = k >> 1, c = e >> 4, st = (e >> 3) & 1, i0 = 2 * (e & 7);
