@@ -66,6 +66,27 @@ template <int A, int OFF>
 __device__ __forceinline__ void a4_read_k(uint32_t lds_addr) {
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(lds_addr), "i"(A), "i"(A + 3), "i"(OFF) : "memory");
 }
+// V fragment half <- LDS (transposed 8-byte read).  The destination is a vector register the compiler allocates, but it
+// does not count this read: a4_wait_v with the right count has to come before the first use.
+template <int OFF>
+__device__ __forceinline__ void a4_read_v(bf16x4& dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void a4_wait_v(bf16x4& a, bf16x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+// LDS reads of one iteration in program order: which gaps issue how many (each gap: its MFMA first, then its reads)
+__device__ constexpr int a4_lds_in_gap(int k) {
+    return (k >= 24 && k < 32 ? 1 : 0) + (k >= 32 && k < 56 && (k & 1) ? 2 : 0) + (k >= 40 && k < 56 ? 1 : 0);
+}
+__device__ constexpr int a4_lds_before(int k) { int n = 0; for (int i = 0; i < k; ++i) n += a4_lds_in_gap(i); return n; }
+// reads still allowed in flight when the MFMA of gap k (the first of fragment mt of group g) needs its fragment
+__device__ constexpr int a4_v_pending(int k) {
+    const int g = (k - 32) >> 3, mt = (k & 7) >> 1;
+    const int done = g == 0 ? a4_lds_before(25 + 2 * mt) + 1 : a4_lds_before(32 + 8 * (g - 1) + 2 * mt + 1) + 2;
+    return a4_lds_before(k) - done;
+}
 // S^T tile += K fragment x Q fragment (both in the accumulator half); FIRST: the product starts from zero
 template <int KA, int QA, bool FIRST>
 __device__ __forceinline__ void a4_mfma_s(f32x16& s) {
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     uint32_t v_addr0[2];
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh)
-        v_addr0[jh] = (uint32_t)(VRING + lds_off128(8 * jh + 4 * h + q4, 2 * gl + (p4 >> 1)) + 8 * (p4 & 1));
+        v_addr0[jh] = lds_base + (uint32_t)(VRING + lds_off128(8 * jh + 4 * h + q4, 2 * gl + (p4 >> 1)) + 8 * (p4 & 1));
 
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
     const float cs = p.scale_log2e;
@@ -331,6 +352,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                 a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), ks == 0>(snext[c][st]);
             } else {
                 constexpr int g = (k - 32) >> 3, st = g >> 1, s2 = g & 1, mt = (k & 7) >> 1, c = k & 1;
+                if constexpr (c == 0) a4_wait_v<a4_v_pending(k)>(vh[mt][0], vh[mt][1]);
                 bf16x8 vf;
                 const bf16x4 lo = vh[mt][0], hi = vh[mt][1];
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
@@ -342,13 +364,13 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
             // after the second MFMA of fragment mt of this one (six gaps ahead of its first use)
             if constexpr (k >= 24 && k < 32) {
                 constexpr int f = k - 24, mt = f >> 1, jh = f & 1;
-                vh[mt][jh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds0 + ((v_it[jh] ^ (uint32_t)(mt << 6)))));
+                a4_read_v<0>(vh[mt][jh], v_it[jh] ^ (uint32_t)(mt << 6));
             }
             if constexpr (k >= 32 && k < 56 && (k & 1) == 1) {
                 constexpr int g = ((k - 32) >> 3) + 1, mt = (k & 7) >> 1;
                 constexpr int voff = (32 * (g >> 1) + 16 * (g & 1)) * ROWB;
-                vh[mt][0] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds0 + ((v_it[0] ^ (uint32_t)(mt << 6)) + voff)));
-                vh[mt][1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, lds0 + ((v_it[1] ^ (uint32_t)(mt << 6)) + voff)));
+                a4_read_v<voff>(vh[mt][0], v_it[0] ^ (uint32_t)(mt << 6));
+                a4_read_v<voff>(vh[mt][1], v_it[1] ^ (uint32_t)(mt << 6));
             }
             // ---- K_{t+2} fragments, one per gap
             if constexpr (k >= 40 && k < 56) {
