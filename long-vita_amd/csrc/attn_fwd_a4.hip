@@ -25,10 +25,10 @@
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((ext_vector_type(4))) uint32_t a4_u32x4;
 
+// (M0 is not restored: nothing else in this kernel uses it, and every statement that needs it sets it itself)
 __device__ __forceinline__ void a4_dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :: "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
 }
 
 // accumulator register numbers
@@ -211,11 +211,13 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     const int64_t k_tile_bytes = (int64_t)BN * p.k_rs * 2, v_tile_bytes = (int64_t)BN * p.v_rs * 2;
     const int rows_avail = min(k_len, p.k_rows_total - k_row0);
     const int prow0 = RPP * PPW * w + lane / CPR;
-    // Piece j of a tile is rows prow0 + RPP j .. of it; since prow0 / 4 is a multiple of 4 the swizzled position of
-    // piece j differs from piece 0's by j in the chunk's low bits.  Rows past the end of the last, partial tile repeat its
-    // last valid row (a per-lane clamp, applied to every tile: two vector instructions, no branch in the loop).
+    // Piece j of a tile is rows prow0 + RPP j .. of it: the same lane offset for every piece (row prow0 of the operand
+    // plus the swizzled position in the row) plus j row steps.  Since
+    // prow0 / 4 is a multiple of 4 the position of piece j differs from piece 0's by j in the chunk's low bits.  Rows
+    // past the end of the last, partial tile are beyond the descriptor's size and arrive as zeros (masked keys anyway).
     const int ch0 = lds_off128(prow0, lane % CPR) - prow0 * ROWB;
-    struct TileSrc { __amdgpu_buffer_rsrc_t rs; int last; int stride; };
+    const int krow0 = prow0 * (int)(p.k_rs * 2), vrow0 = prow0 * (int)(p.v_rs * 2);
+    struct TileSrc { __amdgpu_buffer_rsrc_t rs; int step; };
     // what a tile's four requests share: a descriptor over its valid rows, made of scalars only
     auto tile_src = [&](int t, int isv) __attribute__((always_inline)) {
         int rows = __builtin_amdgcn_readfirstlane(rows_avail - t * BN);
@@ -232,14 +234,12 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         const char* ubase = (const char*)(uintptr_t)(((uint64_t)b_hi << 32) | (uint64_t)b_lo);
         TileSrc ts;
         ts.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)rec), 0x00020000);
-        ts.last = rows > 0 ? rows - 1 : 0;
-        ts.stride = __builtin_amdgcn_readfirstlane((int)(rs_ * 2));
+        ts.step = __builtin_amdgcn_readfirstlane((int)(RPP * rs_ * 2));
         return ts;
     };
     auto issue_piece = [&](const TileSrc& ts, int t, int isv, int j) __attribute__((always_inline)) {
         const uint32_t dst = lds_base + (uint32_t)((isv ? VRING + (t % NVS) * TILEB : (t % NKS) * TILEB) + (PPW * w + j) * 1024);
-        const int row = min(prow0 + RPP * j, ts.last);
-        a4_dma16(ts.rs, (int)__umul24((unsigned)row, (unsigned)ts.stride) + (ch0 ^ (j << 4)), 0, dst);
+        a4_dma16(ts.rs, (isv ? vrow0 : krow0) + (ch0 ^ (j << 4)) + j * ts.step, 0, dst);   // (all of the offset in the part the size check sees)
     };
 
     // ---- LDS read addresses in slot 0
