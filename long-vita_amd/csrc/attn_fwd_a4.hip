@@ -87,6 +87,8 @@ __device__ constexpr int a4_v_pending(int k) {
     const int done = g == 0 ? a4_lds_before(25 + 2 * mt) + 1 : a4_lds_before(32 + 8 * (g - 1) + 2 * mt + 1) + 2;
     return a4_lds_before(k) - done;
 }
+// gaps that carry a staging request and nothing else: 3, 7, .. 31
+__device__ constexpr bool a4_is_dma_gap(int k) { return k < 32 && (k & 3) == 3; }
 // S^T tile += K fragment x Q fragment (both in the accumulator half); FIRST: the product starts from zero
 template <int KA, int QA, bool FIRST>
 __device__ __forceinline__ void a4_mfma_s(f32x16& s) {
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         const bool fast = active && !need_mask && !__any(m_run[0] < -1e29f || m_run[1] < -1e29f);
         const float mc0 = m_run[0] * cs, mc1 = m_run[1] * cs;
         float rs0 = 0.f, rs1 = 0.f;
-        float pvA = 0.f, pvB = 0.f;
+        float pv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         const uint32_t k_it = k_addr0 + kb;                                  // this iteration's slot bases
         const uint32_t v_it[2] = {v_addr0[0] + (uint32_t)vb, v_addr0[1] + (uint32_t)vb};
         bf16x4 vh[MT][2];         // V fragments of ONE group, as the two transposed 8-byte reads of each: a fragment's
@@ -377,26 +379,35 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                 constexpr int f = k - 40, st = f >> 3, ks = f & 7;
                 a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_it ^ (uint32_t)(ks << 5));
             }
-            // ---- staging requests: K tile t+4 (pieces 0-3), V tile t+1 (pieces 0-3), in odd gaps of the S half, where
-            // no LDS read is being issued
+            // ---- staging requests: K tile t+4 (pieces 0-3), V tile t+1 (pieces 0-3), in odd gaps of the S half (no LDS
+            // read is being issued there), four gaps apart; such a gap carries nothing else: its share of the softmax
+            // waits for the next odd gap (a request holds the wave for about 37 cycles, more than a gap has to spare)
             if constexpr (k == 0) src_k = tile_src(t + 4, 0);
             if constexpr (k == 2) src_v = tile_src(t + 1, 1);
-            if constexpr (k == 5 || k == 7 || k == 11 || k == 13) issue_piece(src_k, t + 4, 0, k == 5 ? 0 : k == 7 ? 1 : k == 11 ? 2 : 3);
-            if constexpr (k == 17 || k == 19 || k == 21 || k == 23) issue_piece(src_v, t + 1, 1, (k - 17) >> 1);
-            // ---- softmax share: pair e of the 32 (two scores of S_t per lane)
+            if constexpr (a4_is_dma_gap(k)) {
+                constexpr int j = (k - 3) >> 2;
+                if constexpr (j < 4) issue_piece(src_k, t + 4, 0, j); else issue_piece(src_v, t + 1, 1, j - 4);
+            }
+            // ---- softmax share: pair e of the 32 (two scores of S_t per lane); pairs alternate between two register sets
             {
-                constexpr int e = k >> 1, c = e >> 4, st = (e >> 3) & 1, i0 = 2 * (e & 7);
+                constexpr int e = k >> 1;
                 if constexpr ((k & 1) == 0) {
-                    pvA = fast_exp2(__builtin_fmaf(scur[c][st][i0], cs, c ? -mc1 : -mc0));
-                    pvB = fast_exp2(__builtin_fmaf(scur[c][st][i0 + 1], cs, c ? -mc1 : -mc0));
-                } else {
+                    constexpr int c = e >> 4, st = (e >> 3) & 1, i0 = 2 * (e & 7);
+                    pv[e & 1][0] = fast_exp2(__builtin_fmaf(scur[c][st][i0], cs, c ? -mc1 : -mc0));
+                    pv[e & 1][1] = fast_exp2(__builtin_fmaf(scur[c][st][i0 + 1], cs, c ? -mc1 : -mc0));
+                } else if constexpr (!a4_is_dma_gap(k)) {
                     // (the empty asm statements keep the sums and the cast in THIS gap: left alone, the compiler gathers
                     // them at the end of the iteration and keeps all 64 exponentials alive until then)
-                    if constexpr (c) { rs1 += pvA; rs1 += pvB; asm volatile("" : "+v"(rs1)); }
-                    else { rs0 += pvA; rs0 += pvB; asm volatile("" : "+v"(rs0)); }
-                    uint32_t pw = a4_pack(pvA, pvB);
-                    asm volatile("" : "+v"(pw));
-                    pcur[c][st][i0 >> 3][(i0 & 7) >> 1] = pw;
+                    auto finish = [&](auto E_) __attribute__((always_inline)) {
+                        constexpr int e2 = decltype(E_)::value, c = e2 >> 4, st = (e2 >> 3) & 1, i0 = 2 * (e2 & 7);
+                        if constexpr (c) { rs1 += pv[e2 & 1][0]; rs1 += pv[e2 & 1][1]; asm volatile("" : "+v"(rs1)); }
+                        else { rs0 += pv[e2 & 1][0]; rs0 += pv[e2 & 1][1]; asm volatile("" : "+v"(rs0)); }
+                        uint32_t pw = a4_pack(pv[e2 & 1][0], pv[e2 & 1][1]);
+                        asm volatile("" : "+v"(pw));
+                        pcur[c][st][i0 >> 3][(i0 & 7) >> 1] = pw;
+                    };
+                    if constexpr (k >= 2 && a4_is_dma_gap(k - 2)) finish(std::integral_constant<int, e - 1>{});   // the pair a request displaced
+                    finish(std::integral_constant<int, e>{});
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
