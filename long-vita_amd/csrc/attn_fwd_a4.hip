@@ -440,6 +440,13 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
             issue_piece(tile_src(0, 0), 0, 0, j); issue_piece(tile_src(1, 0), 1, 0, j); issue_piece(tile_src(2, 0), 2, 0, j);
             issue_piece(tile_src(3, 0), 3, 0, j); issue_piece(tile_src(0, 1), 0, 1, j);
         }
+        // Iteration 0 multiplies P = 0 by the V slot of "tile -1", which nothing has written: zero it (0 x NaN is NaN).
+        {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+                *(LDS_PTR(f32x4, lds0 + VRING + (NVS - 1) * TILEB + (PPW * w + j) * 1024 + lane * 16)) = z;
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define A4_RK(st, ks, off) a4_read_k<a4_K(st, ks), st * 32 * ROWB + off>(k_addr0 ^ (uint32_t)(ks << 5));
 #define A4_RK16(off) A4_RK(0, 0, off) A4_RK(0, 1, off) A4_RK(0, 2, off) A4_RK(0, 3, off) A4_RK(0, 4, off) A4_RK(0, 5, off) A4_RK(0, 6, off) \
