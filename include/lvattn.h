@@ -114,7 +114,7 @@ int lvattn_fwd_dense(const void* q, const void* k, const void* v, void* out, flo
                      int64_t lse_stride, float softmax_scale, int causal, void* stream);
 
 /* Tuning / test hook, no counterpart in the reference: choose the forward kernel for later lvattn_fwd calls of this
- * process ("default", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
+ * process ("default", "a4", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
  * is read on first use otherwise).  Not thread-safe against concurrent launches. */
 int lvattn_select_fwd_kernel(const char* name);
 /* The same for the backward: dq in {"default", "pp", "lockstep"}, dkdv in {"default", "rs" (role-split, two units per

@@ -24,10 +24,12 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" int lvattn_abi_version(void) { return 1; }
 
-// Forward kernel choice.  Default: the ping-pong kernel for head dim 128 and the lockstep kernel for
-// head dim 64 (each is the faster one there: +13 % at d = 128, -16 % at d = 64).  The environment variable
-// LVATTN_FWD_KERNEL=pp / lockstep forces one of them for every head dim.
-static int fwd_kernel_code(const char* e) {   // 0 default, 1 ping-pong (32x32x16 MFMAs), 2 lockstep, 3 ping-pong on 16x16x32 MFMAs
+// Forward kernel choice.  Default: the one-wave-per-SIMD kernel ("a4") for head dim 128 and the lockstep kernel for
+// head dim 64; the ping-pong kernel ("pp") carries the fused rotary embedding and stays selectable, as do pp16 and
+// lockstep (a4 +1.8 % over pp at 1M tokens, pp +13 % over lockstep at d = 128, lockstep +16 % over pp at d = 64).  The
+// environment variable LVATTN_FWD_KERNEL=a4 / pp / pp16 / lockstep forces one (a4 and pp16 exist for d = 128 only:
+// other head dims then take their default).
+static int fwd_kernel_code(const char* e) {   // 0 default, 1 ping-pong (32x32x16 MFMAs), 2 lockstep, 3 ping-pong on 16x16x32 MFMAs, 4 one wave per SIMD
     if (!e) return 0;
     return !strcmp(e, "pp") ? 1 : (!strcmp(e, "lockstep") ? 2 : (!strcmp(e, "pp16") ? 3 : (!strcmp(e, "a4") ? 4 : 0)));
 }
@@ -57,11 +59,8 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
     return LV_OK;
 }
 static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
-static bool fwd_a4(int d) { return d == 128 && fwd_kernel_override() == 4; }
-static bool fwd_pingpong(int d) {
-    const int o = fwd_kernel_override();
-    return o == 1 || (o == 0 && d == 128);
-}
+static bool fwd_a4(int d) { return d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0); }
+static bool fwd_pingpong(int d) { return fwd_kernel_override() == 1; }
 // Query rows per forward work item: 256 (8 waves per workgroup); with the lockstep kernel forced,
 // LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
 // Follows lvattn_select_fwd_kernel: descriptors must be (re)built with the block size in force at launch time.

@@ -256,7 +256,7 @@ def test_full_size_1m_prefill_rows_against_oracle_and_decode_kernel():
     assert (dlse[0] - lse[:, S - 1]).abs().max().item() <= LSE_TOL
 
 
-@pytest.mark.parametrize("kernel", ["pp", "pp16", "lockstep"])
+@pytest.mark.parametrize("kernel", ["a4", "pp", "pp16", "lockstep"])
 def test_every_forward_kernel_variant(kernel):
     """The forward kernels that are not the default for a head dim stay selectable (LVATTN_FWD_KERNEL or
     lvattn_select_fwd_kernel) and give the same results to tolerance."""

@@ -263,7 +263,7 @@ def test_ring_hip_backend_packed_segments(cp, cu):
 
 
 @pytest.mark.parametrize("cp,cu", [(2, None), (4, None), (4, [0, 700, 2100, 2101, 3900, 4096])])
-def test_ring_forward_with_rotary_embedding_folded_in(cp, cu):
+def test_ring_forward_with_rotary_embedding_folded_in(cp, cu, kernel_with_rotation):
     """Ring forward on UNROTATED q / k with the rotary tables of each rank's rows (keys rotated while they are packed
     into the ring message, queries inside the block kernels) equals, bit for bit, the ring forward on q / k rotated
     beforehand by the standalone kernel."""
@@ -357,7 +357,7 @@ def _rope_case(S, seed):
 
 
 @pytest.mark.parametrize("cp,cu", [(2, None), (4, [0, 700, 2100, 2101, 3900, 4096])])
-def test_ring_rope_forward_backward_equals_rotating_first(cp, cu):
+def test_ring_rope_forward_backward_equals_rotating_first(cp, cu, kernel_with_rotation):
     """The ring with the rotary embedding folded in (ring_rope_forward / ring_rope_backward, what the autograd function
     of ringattn_context_parallel(rope=...) runs) against the plain ring on q / k rotated beforehand with the transposed
     rotation applied to its dq / dk afterwards: out, lse and dq / dk / dv bit for bit, over virtual ranks."""
@@ -391,7 +391,7 @@ def test_ring_rope_forward_backward_equals_rotating_first(cp, cu):
     assert all(run_virtual_ranks(cp, body))
 
 
-def test_ring_rope_autograd_entry_point_single_rank():
+def test_ring_rope_autograd_entry_point_single_rank(kernel_with_rotation):
     """ringattn_context_parallel(..., rope=(cos, sin)) under torch autograd (one rank: the autograd engine runs every
     backward of a device on one thread, so virtual ranks cannot exchange inside it) against apply-rope-first through the
     same entry point, packed segments included: out and the gradients of the unrotated q, k, v bit for bit."""

@@ -136,7 +136,7 @@ def _qwen_case(S, seed, HQ=10, HKV=2, D=128):
 
 
 @pytest.mark.parametrize("cu", [[0, 777], [0, 258, 1290, 1291, 3000], [0, 513, 1024]])
-def test_rotation_inside_the_attention_kernel_equals_the_two_pass_path(cu):
+def test_rotation_inside_the_attention_kernel_equals_the_two_pass_path(cu, kernel_with_rotation):
     """The query rotation folded into the attention kernel (lvattn_fwd_rope) + the standalone K rotation against the
     two-pass path (lv_rope on q and k, then lvattn_fwd / lvattn_bwd): out, lse, the rotated queries the kernel writes
     out, and dq / dk / dv must be IDENTICAL bit for bit; and within the attention tolerance of the float64 oracle on the
@@ -215,7 +215,7 @@ def test_fused_rope_argument_errors():
         ops.rope_pack_kv(q, q, tab, tab)
 
 
-def test_rope_flash_attention_entry(golden_dir):
+def test_rope_flash_attention_entry(golden_dir, kernel_with_rotation):
     """The Megatron-shaped entry ([s, 1, h, d] tensors, fp32 angle tensor) equals apply_rotary_pos_emb followed by the
     packed attention, bit for bit."""
     from types import SimpleNamespace
