@@ -15,20 +15,34 @@
 //
 // The loop is software-pipelined: iteration t holds O^T += V_{t-1}^T P_{t-1}^T, S_{t+1}^T = K_{t+1} Q^T and the softmax of
 // S_t, the vector work spread over the 64 MFMA gaps of the iteration; one workgroup barrier per 64-key tile.
-// K tiles live in a 4-slot LDS ring, V tiles in a 3-slot one; iteration t requests K tile t+4 and V tile t+1 by direct
-// global -> LDS loads (each wave a quarter of each), a counted s_waitcnt vmcnt before the barrier leaves the newest
-// iteration's requests in flight.  K runs further ahead because its fragments move into the accumulator registers one
-// iteration before the S product that reads them.
+// K and V tiles live in 4-slot LDS rings; iteration t requests K tile t+4 and V tile t+2 by direct global -> LDS loads
+// (each wave a quarter of each), a counted s_waitcnt vmcnt before the barrier leaves the newest iteration's requests in
+// flight.  K runs further ahead because its fragments move into the accumulator registers one iteration before the S
+// product that reads them.
+//
+// One wave per SIMD issues every instruction of its SIMD, one per four cycles at best whatever the kind, so the loop is
+// kept short: it is unrolled four times, which makes every ring slot a compile-time constant (LDS addresses are one lane
+// register plus an immediate, staging destinations one scalar add into M0), the staging descriptors are advanced
+// instead of rebuilt, and the per-tile decisions are one scalar compare against a precomputed tile index.
 #include "internal.h"
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((ext_vector_type(4))) uint32_t a4_u32x4;
 
-// (M0 is not restored: nothing else in this kernel uses it, and every statement that needs it sets it itself)
-__device__ __forceinline__ void a4_dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                 :: "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
+// One staging request: piece J of a tile (1 KiB per wave).  M0 = wave_base + DST (the LDS destination), the lane's
+// global offset is its offset in piece 0 with J XORed into the chunk bits plus J row steps; the address instruction sits
+// in the wait state that the M0 write needs before the request.  M0 is not restored: nothing else here uses it.
+template <int DST, int J>
+__device__ __forceinline__ void a4_dma(a4_u32x4 rs, int voff0, int jstep, uint32_t wave_base) {
+    if constexpr (J == 0) {
+        asm volatile("s_add_i32 m0, %2, %c3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                     :: "v"(voff0), "s"(rs), "s"(wave_base), "i"(DST) : "memory", "scc");
+    } else {
+        int voff;
+        asm volatile("s_add_i32 m0, %4, %c5\n\tv_xad_u32 %0, %1, %c6, %2\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds"
+                     : "=&v"(voff) : "v"(voff0), "s"(jstep), "s"(rs), "s"(wave_base), "i"(DST), "i"(J << 4) : "memory", "scc");
+    }
 }
 
 // accumulator register numbers
@@ -67,28 +81,29 @@ __device__ __forceinline__ void a4_read_k(uint32_t lds_addr) {
     asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(lds_addr), "i"(A), "i"(A + 3), "i"(OFF) : "memory");
 }
 // V fragment half <- LDS (transposed 8-byte read).  The destination is a vector register the compiler allocates, but it
-// does not count this read: a4_wait_v with the right count has to come before the first use.
+// does not count this read: the MFMA that uses it carries the s_waitcnt with the right count (a4_mfma_o).
 template <int OFF>
 __device__ __forceinline__ void a4_read_v(bf16x4& dst, uint32_t lds_addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void a4_wait_v(bf16x4& a, bf16x4& b) {
-    asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(a), "+v"(b) : "i"(N));
+// LDS reads of one iteration, by gap (each gap: its MFMA first, then its V reads, then its K read).  All sit in even
+// gaps; the odd ones are full with the second half of the softmax share.
+//   K_{t+2} fragment f = (st, ks) in gap 6 + 2 f: the S product is done with that register two gaps earlier at the latest
+//   V_{t-1} fragment (g, mt): group 0 in gaps 24 .. 30, group g >= 1 in the gap after the MFMAs of fragment (g - 1, mt),
+//   whose registers it reuses, six gaps ahead of its own MFMAs
+__device__ constexpr int a4_nk(int k) { return (!(k & 1) && k >= 6 && k <= 36) ? 1 : 0; }
+__device__ constexpr int a4_nv(int k) { return (!(k & 1) && ((k >= 24 && k <= 30) || (k >= 34 && k <= 56))) ? 2 : 0; }
+__device__ constexpr int a4_lds_before(int k) { int n = 0; for (int i = 0; i < k; ++i) n += a4_nk(i) + a4_nv(i); return n; }
+__device__ constexpr int a4_v_gap(int g, int mt) { return g == 0 ? 24 + 2 * mt : 32 + 8 * (g - 1) + 2 * mt + 2; }
+// reads allowed in flight when the MFMA of gap k (PV half, group g) needs the fragments up to (g, mt_last)
+__device__ constexpr int a4_v_pending(int k, int mt_last) {
+    return a4_lds_before(k) - (a4_lds_before(a4_v_gap((k - 32) >> 3, mt_last)) + 2);
 }
-// LDS reads of one iteration in program order: which gaps issue how many (each gap: its MFMA first, then its reads)
-__device__ constexpr int a4_lds_in_gap(int k) {
-    return (k >= 24 && k < 32 ? 1 : 0) + (k >= 32 && k < 56 && (k & 1) ? 2 : 0) + (k >= 40 && k < 56 ? 1 : 0);
+// the staging requests of an iteration: K pieces 0-3 in gaps 0, 2, 4, 12 and V pieces 0-3 in gaps 20, 58, 60, 62 (even
+// gaps with no or one LDS read); the K descriptor moves on in gap 14, the V descriptor in gap 16
+__device__ constexpr int a4_dma_piece(int k) {   // 0-3: K piece, 4-7: V piece, -1: none
+    return k == 0 ? 0 : k == 2 ? 1 : k == 4 ? 2 : k == 12 ? 3 : k == 20 ? 4 : k == 58 ? 5 : k == 60 ? 6 : k == 62 ? 7 : -1;
 }
-__device__ constexpr int a4_lds_before(int k) { int n = 0; for (int i = 0; i < k; ++i) n += a4_lds_in_gap(i); return n; }
-// reads still allowed in flight when the MFMA of gap k (the first of fragment mt of group g) needs its fragment
-__device__ constexpr int a4_v_pending(int k) {
-    const int g = (k - 32) >> 3, mt = (k & 7) >> 1;
-    const int done = g == 0 ? a4_lds_before(25 + 2 * mt) + 1 : a4_lds_before(32 + 8 * (g - 1) + 2 * mt + 1) + 2;
-    return a4_lds_before(k) - done;
-}
-// gaps that carry a staging request and nothing else: 3, 7, .. 31
-__device__ constexpr bool a4_is_dma_gap(int k) { return k < 32 && (k & 3) == 3; }
 // S^T tile += K fragment x Q fragment (both in the accumulator half); FIRST: the product starts from zero
 template <int KA, int QA, bool FIRST>
 __device__ __forceinline__ void a4_mfma_s(f32x16& s) {
@@ -97,10 +112,14 @@ __device__ __forceinline__ void a4_mfma_s(f32x16& s) {
     else
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
 }
-// O^T tile += V fragment x P fragment (vector registers)
-template <int OA>
+// O^T tile += V fragment x P fragment (vector registers); WAIT >= 0: first let all but WAIT LDS reads land
+template <int OA, int WAIT>
 __device__ __forceinline__ void a4_mfma_o(bf16x8 vf, bf16x8 pf) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf), "v"(pf), "i"(OA), "i"(OA + 15));
+    if constexpr (WAIT >= 0)
+        asm volatile("s_waitcnt lgkmcnt(%c4)\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
+                     :: "v"(vf), "v"(pf), "i"(OA), "i"(OA + 15), "i"(WAIT) : "memory");
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf), "v"(pf), "i"(OA), "i"(OA + 15));
 }
 // two fp32 -> one dword of two bf16 (round to nearest even), the first in the low half
 __device__ __forceinline__ uint32_t a4_pack(float a, float b) {
@@ -108,6 +127,12 @@ __device__ __forceinline__ uint32_t a4_pack(float a, float b) {
     bf16x2_ v;
     v[0] = (__bf16)a; v[1] = (__bf16)b;
     return __builtin_bit_cast(uint32_t, v);
+}
+// The same as a store into a register that already holds a value: on the rare paths (exact pass, tiles past the wave's
+// rows) P is overwritten IN the registers the optimistic pass filled, so that the two paths meet without a copy on the
+// common one.
+__device__ __forceinline__ void a4_pack_into(uint32_t& dst, float a, float b) {
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "+v"(dst) : "v"(a), "v"(b));
 }
 template <int N>
 __device__ __forceinline__ void a4_nop() { asm volatile("s_nop %c0" :: "i"(N - 1)); }
@@ -129,8 +154,8 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     constexpr int ROWB = D * 2;
     constexpr int TILEB = BN * ROWB;  // 16 KiB
     constexpr int CPR = D / 8;
-    constexpr int NKS = 4, NVS = 3;   // ring slots: K tiles t+1 .. t+4, V tiles t-1 .. t+1 around iteration t
-    constexpr int VRING = NKS * TILEB;  // byte offset of the V ring
+    constexpr int NS = 4;             // ring slots: K tiles t+1 .. t+4, V tiles t-1 .. t+2 around iteration t
+    constexpr int KRING = NS * TILEB; // byte offset of the K ring (the V ring comes first: every read offset fits an immediate)
     constexpr int RPP = 64 / CPR;     // rows per 1-KiB piece: 4
     constexpr int PPW = 4;            // pieces per wave per tile and operand
     constexpr float RESCALE_LOG2 = 8.0f;
@@ -210,55 +235,62 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     // ---- staging: wave w brings rows 16w .. 16w+15 of every K tile and of every V tile (4 pieces each)
     const char* kbase = reinterpret_cast<const char*>(p.k + (int64_t)kvh * p.k_hs + (int64_t)k_row0 * p.k_rs);
     const char* vbase = reinterpret_cast<const char*>(p.v + (int64_t)kvh * p.v_hs + (int64_t)k_row0 * p.v_rs);
-    const int64_t k_tile_bytes = (int64_t)BN * p.k_rs * 2, v_tile_bytes = (int64_t)BN * p.v_rs * 2;
     const int rows_avail = min(k_len, p.k_rows_total - k_row0);
     const int prow0 = RPP * PPW * w + lane / CPR;
-    // Piece j of a tile is rows prow0 + RPP j .. of it: the same lane offset for every piece (row prow0 of the operand
-    // plus the swizzled position in the row) plus j row steps.  Since
-    // prow0 / 4 is a multiple of 4 the position of piece j differs from piece 0's by j in the chunk's low bits.  Rows
-    // past the end of the last, partial tile are beyond the descriptor's size and arrive as zeros (masked keys anyway).
+    // Piece j of a tile is rows prow0 + RPP j .. of it.  The lane's offset in piece 0 is its row times the row stride
+    // plus its swizzled position in the row; since prow0 / 4 is a multiple of 4, piece j differs by j in the low bits
+    // of the position (an XOR: row strides are multiples of 256 bytes here, the launcher sees to that) plus j row steps.
+    // Rows past the end of the last, partial tile are beyond the descriptor's size and arrive as zeros (masked keys).
     const int ch0 = lds_off128(prow0, lane % CPR) - prow0 * ROWB;
-    const int krow0 = prow0 * (int)(p.k_rs * 2), vrow0 = prow0 * (int)(p.v_rs * 2);
-    struct TileSrc { __amdgpu_buffer_rsrc_t rs; int step; };
-    // what a tile's four requests share: a descriptor over its valid rows, made of scalars only
-    auto tile_src = [&](int t, int isv) __attribute__((always_inline)) {
-        int rows = __builtin_amdgcn_readfirstlane(rows_avail - t * BN);
-        rows = rows < 0 ? 0 : rows;
+    const int kvo0 = prow0 * (int)(p.k_rs * 2) + ch0, vvo0 = prow0 * (int)(p.v_rs * 2) + ch0;
+    const int k_row_bytes = __builtin_amdgcn_readfirstlane((int)(p.k_rs * 2)), v_row_bytes = __builtin_amdgcn_readfirstlane((int)(p.v_rs * 2));
+    const int kstep = RPP * k_row_bytes, vstep = RPP * v_row_bytes;
+    const int kstep2 = 2 * kstep, kstep3 = 3 * kstep, vstep2 = 2 * vstep, vstep3 = 3 * vstep;
+    const uint32_t wave_base = lds_base + (uint32_t)(PPW * w * 1024);
+    // A tile's descriptor: base = its first row, size = its valid rows x the row stride (a row's 256 bytes end before the
+    // next row starts, so exactly the valid rows pass the range check).  Kept as four scalars and moved on tile by tile.
+    struct Stage { a4_u32x4 rs; int rem; };
+    auto stage_at = [&](const char* base, int64_t row_elems, int t) __attribute__((always_inline)) {
+        const uint64_t b = (uint64_t)(uintptr_t)(base + (int64_t)t * BN * row_elems * 2);
+        Stage st;
+        st.rem = rows_avail - t * BN;
+        const int rows = st.rem < 0 ? 0 : (st.rem > BN ? BN : st.rem);
+        st.rs[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        st.rs[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) & 0xffffu;
+        st.rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane(rows * (int)(row_elems * 2));
+        st.rs[3] = 0x00020000u;
+        return st;
+    };
+    auto stage_next = [&](Stage& st, int row_bytes) __attribute__((always_inline)) {
+        const uint64_t b = (((uint64_t)st.rs[1] << 32) | st.rs[0]) + (uint64_t)(uint32_t)(BN * row_bytes);
+        st.rs[0] = (uint32_t)b;
+        st.rs[1] = (uint32_t)(b >> 32);
+        st.rem -= BN;
+        int rows = st.rem < 0 ? 0 : st.rem;
         asm volatile("" : "+s"(rows));            // (two scalar steps: written as one clamp it becomes a vector med3)
         rows = rows > BN ? BN : rows;
-        const int64_t rs_ = isv ? p.v_rs : p.k_rs;
-        uint32_t rec = (uint32_t)(rows - 1) * (uint32_t)(rs_ * 2) + ROWB;
-        rec = rows ? rec : 0u;
-        const char* base = isv ? vbase + t * v_tile_bytes : kbase + t * k_tile_bytes;
-        const uint64_t b64 = (uint64_t)(uintptr_t)base;
-        const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32));
-        const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
-        const char* ubase = (const char*)(uintptr_t)(((uint64_t)b_hi << 32) | (uint64_t)b_lo);
-        TileSrc ts;
-        ts.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ubase), 0, (uint32_t)__builtin_amdgcn_readfirstlane((int)rec), 0x00020000);
-        ts.step = __builtin_amdgcn_readfirstlane((int)(RPP * rs_ * 2));
-        return ts;
+        st.rs[2] = (uint32_t)(rows * row_bytes);
     };
-    auto issue_piece = [&](const TileSrc& ts, int t, int isv, int j) __attribute__((always_inline)) {
-        const uint32_t dst = lds_base + (uint32_t)((isv ? VRING + (t % NVS) * TILEB : (t % NKS) * TILEB) + (PPW * w + j) * 1024);
-        a4_dma16(ts.rs, (isv ? vrow0 : krow0) + (ch0 ^ (j << 4)) + j * ts.step, 0, dst);   // (all of the offset in the part the size check sees)
-    };
+    // piece j of K tile -> K slot, of V tile -> V slot (prologue form: slot and piece are compile-time there too)
+#define A4_DMA_K(st_, slot, j) a4_dma<KRING + (slot) * TILEB + (j) * 1024, j>((st_).rs, kvo0, (j) == 1 ? kstep : (j) == 2 ? kstep2 : kstep3, wave_base)
+#define A4_DMA_V(st_, slot, j) a4_dma<(slot) * TILEB + (j) * 1024, j>((st_).rs, vvo0, (j) == 1 ? vstep : (j) == 2 ? vstep2 : vstep3, wave_base)
 
-    // ---- LDS read addresses in slot 0
+    // ---- LDS read addresses in slot 0 of each ring
     // The XOR swizzle acts on address bits 4..7 only and every slot starts on a multiple of 256 bytes, so the address of
     // fragment ks (chunk 2 ks + h) is the address of fragment 0 with ks XORed into bits 5..7: one register instead of eight.
-    const uint32_t k_addr0 = lds_base + (uint32_t)lds_off128(r, h);
+    const uint32_t k_addr0 = lds_base + (uint32_t)(KRING + lds_off128(r, h));
     const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gl = (lane >> 4) & 1;
     // likewise the d sub-tile mt (chunk 4 mt + ...) of a V read is bits 6..7
     uint32_t v_addr0[2];
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh)
-        v_addr0[jh] = lds_base + (uint32_t)(VRING + lds_off128(8 * jh + 4 * h + q4, 2 * gl + (p4 >> 1)) + 8 * (p4 & 1));
+        v_addr0[jh] = lds_base + (uint32_t)(lds_off128(8 * jh + 4 * h + q4, 2 * gl + (p4 >> 1)) + 8 * (p4 & 1));
 
+    // running maximum in the exponent's units (score x scale x log2 e) and running sum, per column block
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
     const float cs = p.scale_log2e;
     f32x16 sA[2][2], sB[2][2];        // S^T of two consecutive tiles: [column block][32-key half]
-    a4_u32x4 pA[2][2][2], pB[2][2][2];  // P^T (bf16 pairs) of two consecutive tiles: [column block][half][16-key quarter]
+    uint32_t pA[2][2][2][4], pB[2][2][2][4];  // P^T (bf16 pairs) of two consecutive tiles: [column block][half][16-key quarter]
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                 for (int i = 0; i < 4; ++i) { pA[c][st][s2][i] = 0u; pB[c][st][s2][i] = 0u; }
 
     // exact softmax of tile t held in sc (mask, row maximum, deferred rescale) -> pf; updates m_run / l_run / O
-    auto softmax_exact = [&](f32x16 (&sc)[2][2], a4_u32x4 (&pf)[2][2][2], int t, bool need_mask) __attribute__((always_inline)) {
+    auto softmax_exact = [&](f32x16 (&sc)[2][2], uint32_t (&pf)[2][2][2][4], int t, bool need_mask) __attribute__((always_inline)) {
         const int kb0 = t * BN;
         // (a rare path: the lane's row and column half come from a lane id read here, not from registers kept for it)
         int lane_x;
@@ -294,16 +326,16 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc[c][0][i]);
 #pragma unroll
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[c][1][i]);
-            mx = pair32_max(mx);
+            mx = pair32_max(mx) * cs;
             const float m_new = fmaxf(m_run[c], mx);
-            const bool grow = (m_new - m_run[c]) * cs > RESCALE_LOG2;
+            const bool grow = (m_new - m_run[c]) > RESCALE_LOG2;
             if (__any(grow)) {
-                const float alpha = fast_exp2((m_run[c] - m_new) * cs);
+                const float alpha = fast_exp2(m_run[c] - m_new);
                 m_run[c] = m_new;
                 l_run[c] *= alpha;
                 if (c == 0) a4_scale<0, 64>(alpha); else a4_scale<64, 64>(alpha);
             }
-            const float mc = m_run[c] * cs;
+            const float mc = m_run[c];
             float rs = 0.f;
 #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -312,40 +344,61 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                     const float pa = fast_exp2(__builtin_fmaf(sc[c][st][i], cs, -mc));
                     const float pb = fast_exp2(__builtin_fmaf(sc[c][st][i + 1], cs, -mc));
                     rs += pa + pb;
-                    pf[c][st][i >> 3][(i & 7) >> 1] = a4_pack(pa, pb);
+                    a4_pack_into(pf[c][st][i >> 3][(i & 7) >> 1], pa, pb);
                 }
             l_run[c] += rs;
         }
     };
 
+    // Tiles below t_fast need no mask for any row of this wave and are live for it: the optimistic pass alone handles them
+    // (once every row has seen a key: all_seen).  Everything else, the diagonal tiles, the last partial tile, tiles past
+    // the wave's rows, goes through the decisions at the end of the iteration.
+    int t_fast = min(my_nkt, min((64 * w + shift + 1) >> 6, k_len >> 6));
+    t_fast = t_fast < 0 ? 0 : t_fast;
+    int t_fast_now = 0;               // t_fast once all_seen, 0 before
+
+    Stage kst = stage_at(kbase, p.k_rs, 4), vst = stage_at(vbase, p.v_rs, 1);   // tile 4 for iteration 0; V moves on before its use
+
     // One iteration (one barrier): 64 MFMAs, each followed by its share of the other work ("gap" k = 0 .. 63):
     //   gaps  0-31  S_{t+1}^T = K_{t+1} Q^T       segment (st, kh), then (ks, c); the K fragments are in a[192:255] already
     //   gaps 32-63  O^T += V_{t-1}^T P_{t-1}^T   group g = (st, s2), then (mt, c)
-    //   every gap   softmax of S_t -> P_t against the running maximum (optimistic pass): even gaps the two exponentials
-    //               of a pair of scores, odd gaps the row sums and the cast; a tile that needs masking or whose sums
-    //               come out too large is redone exactly after the gaps (S_t is still intact)
-    //   gaps 24-55  the V fragments: group 0 before the PV half, then fragment mt of the next group behind this group's
-    //   gaps 40-55  K_{t+2} fragments -> a[192:255] (every S product of this iteration has been issued)
-    //   8 gaps      the staging requests: K tile t+4, V tile t+1
-    auto iteration = [&](int t, f32x16 (&scur)[2][2], f32x16 (&snext)[2][2], a4_u32x4 (&pprev)[2][2][2], a4_u32x4 (&pcur)[2][2][2])
-                         __attribute__((always_inline)) {
+    //   every gap   one score of S_t per lane: exp2(s x scale - running maximum) (optimistic pass; a tile that needs
+    //               masking or whose sums come out too large is redone exactly after the gaps, S_t is still intact)
+    //   odd gaps    the pair of exponentials finished two gaps earlier: row sum, cast to bf16 -> P_t
+    //   even gaps   LDS reads (V_{t-1} fragments, K_{t+2} fragments -> a[192:255]) and the staging requests (K tile t+4,
+    //               V tile t+2), on the schedule of a4_nk / a4_nv / a4_dma_piece
+    // SLOT = t mod 4 fixes every ring slot at compile time.
+    auto iteration = [&](auto SLOT_, int t) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(SLOT_)::value;
+        f32x16 (&scur)[2][2] = (SLOT & 1) ? sB : sA;
+        f32x16 (&snext)[2][2] = (SLOT & 1) ? sA : sB;
+        uint32_t (&pprev)[2][2][2][4] = (SLOT & 1) ? pA : pB;
+        uint32_t (&pcur)[2][2][2][4] = (SLOT & 1) ? pB : pA;
         // everything older than the previous iteration's requests has landed (K tile t+2, V tile t-1)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const int vb = ((t + NVS - 1) % NVS) * TILEB;             // slot of V tile t-1 (t = 0: P is zero, whatever is read)
-        const uint32_t kb = (uint32_t)(((t + 2) % NKS) * TILEB);  // slot of K tile t+2
-        const bool active = (t < my_nkt);
-        const int kb0 = t * BN;
-        const bool need_mask = (kb0 + BN - 1 > 64 * w + shift) || (kb0 + BN > k_len);
-        const bool fast = active && !need_mask && !__any(m_run[0] < -1e29f || m_run[1] < -1e29f);
-        const float mc0 = m_run[0] * cs, mc1 = m_run[1] * cs;
+        constexpr int KOFF = ((SLOT + 2) & 3) * TILEB;            // slot of K tile t+2
+        constexpr int VOFF = ((SLOT + 3) & 3) * TILEB;            // slot of V tile t-1 (t = 0: zeros, P is zero as well)
         float rs0 = 0.f, rs1 = 0.f;
-        float pv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        const uint32_t k_it = k_addr0 + kb;                                  // this iteration's slot bases
-        const uint32_t v_it[2] = {v_addr0[0] + (uint32_t)vb, v_addr0[1] + (uint32_t)vb};
+        float pv[4];              // exponentials in flight: score k in pv[k & 3]
         bf16x4 vh[MT][2];         // V fragments of ONE group, as the two transposed 8-byte reads of each: a fragment's
                                   // registers are re-read for the next group as soon as its two MFMAs have been issued
-        TileSrc src_k, src_v;     // set up in gaps 0 and 2 (scalar work, behind the first MFMAs instead of ahead of them)
+        // row sum and cast of the pair of scores (E, E + 1)
+        auto finish = [&](auto E_) __attribute__((always_inline)) {
+            constexpr int e = decltype(E_)::value, c = e >> 5, st = (e >> 4) & 1, i0 = e & 15;
+            // (the empty asm statements keep the sums and the cast in THIS gap: left alone, the compiler gathers them at
+            // the end of the iteration and keeps all 64 exponentials alive until then)
+            if constexpr (c) {
+                if constexpr (e == 32) rs1 = pv[e & 3] + pv[(e + 1) & 3]; else { rs1 += pv[e & 3]; rs1 += pv[(e + 1) & 3]; }
+                asm volatile("" : "+v"(rs1));
+            } else {
+                if constexpr (e == 0) rs0 = pv[e & 3] + pv[(e + 1) & 3]; else { rs0 += pv[e & 3]; rs0 += pv[(e + 1) & 3]; }
+                asm volatile("" : "+v"(rs0));
+            }
+            uint32_t pw = a4_pack(pv[e & 3], pv[(e + 1) & 3]);
+            asm volatile("" : "+v"(pw));
+            pcur[c][st][i0 >> 3][(i0 & 7) >> 1] = pw;
+        };
         a4_static_for<0, 64>([&](auto K_) __attribute__((always_inline)) {
             constexpr int k = decltype(K_)::value;
             // ---- the MFMA of this gap
@@ -354,73 +407,68 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                 a4_mfma_s<a4_K(st, ks), a4_Q(c, ks), ks == 0>(snext[c][st]);
             } else {
                 constexpr int g = (k - 32) >> 3, st = g >> 1, s2 = g & 1, mt = (k & 7) >> 1, c = k & 1;
-                if constexpr (c == 0) a4_wait_v<a4_v_pending(k)>(vh[mt][0], vh[mt][1]);
                 bf16x8 vf;
                 const bf16x4 lo = vh[mt][0], hi = vh[mt][1];
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                a4_mfma_o<a4_O(c, mt)>(vf, __builtin_bit_cast(bf16x8, pprev[c][st][s2]));
+                // (fragments mt and mt + 1 are waited for together: half the waits)
+                constexpr int wait = (c == 0 && (mt & 1) == 0) ? a4_v_pending(k, mt + 1) : -1;
+                const a4_u32x4 pq = {pprev[c][st][s2][0], pprev[c][st][s2][1], pprev[c][st][s2][2], pprev[c][st][s2][3]};
+                a4_mfma_o<a4_O(c, mt), wait>(vf, __builtin_bit_cast(bf16x8, pq));
             }
             __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its gap's fillers behind it
-            // ---- V fragments: group 0's eight reads in gaps 24-31; in the PV half fragment mt of the NEXT group right
-            // after the second MFMA of fragment mt of this one (six gaps ahead of its first use)
-            if constexpr (k >= 24 && k < 32) {
-                constexpr int f = k - 24, mt = f >> 1, jh = f & 1;
-                a4_read_v<0>(vh[mt][jh], v_it[jh] ^ (uint32_t)(mt << 6));
+            // ---- V fragments
+            if constexpr (a4_nv(k) != 0) {
+                constexpr int g = k < 32 ? 0 : (k - 34) / 8 + 1, mt = k < 32 ? (k - 24) >> 1 : ((k - 34) & 7) >> 1;
+                static_assert(a4_v_gap(g, mt) == k, "V read schedule");
+                constexpr int voff = VOFF + (32 * (g >> 1) + 16 * (g & 1)) * ROWB;
+                a4_read_v<voff>(vh[mt][0], v_addr0[0] ^ (uint32_t)(mt << 6));
+                a4_read_v<voff>(vh[mt][1], v_addr0[1] ^ (uint32_t)(mt << 6));
             }
-            if constexpr (k >= 32 && k < 56 && (k & 1) == 1) {
-                constexpr int g = ((k - 32) >> 3) + 1, mt = (k & 7) >> 1;
-                constexpr int voff = (32 * (g >> 1) + 16 * (g & 1)) * ROWB;
-                a4_read_v<voff>(vh[mt][0], v_it[0] ^ (uint32_t)(mt << 6));
-                a4_read_v<voff>(vh[mt][1], v_it[1] ^ (uint32_t)(mt << 6));
+            // ---- K_{t+2} fragments
+            if constexpr (a4_nk(k) != 0) {
+                constexpr int f = (k - 6) >> 1, st = f >> 3, ks = f & 7;
+                a4_read_k<a4_K(st, ks), KOFF + st * 32 * ROWB>(k_addr0 ^ (uint32_t)(ks << 5));
             }
-            // ---- K_{t+2} fragments, one per gap
-            if constexpr (k >= 40 && k < 56) {
-                constexpr int f = k - 40, st = f >> 3, ks = f & 7;
-                a4_read_k<a4_K(st, ks), st * 32 * ROWB>(k_it ^ (uint32_t)(ks << 5));
+            // ---- staging requests: K tile t+4 into the slot of K tile t, V tile t+2 into the slot of V tile t-2
+            if constexpr (a4_dma_piece(k) >= 0) {
+                constexpr int pc = a4_dma_piece(k);
+                if constexpr (pc == 0) A4_DMA_K(kst, SLOT, 0);
+                else if constexpr (pc == 1) A4_DMA_K(kst, SLOT, 1);
+                else if constexpr (pc == 2) A4_DMA_K(kst, SLOT, 2);
+                else if constexpr (pc == 3) A4_DMA_K(kst, SLOT, 3);
+                else if constexpr (pc == 4) A4_DMA_V(vst, (SLOT + 2) & 3, 0);
+                else if constexpr (pc == 5) A4_DMA_V(vst, (SLOT + 2) & 3, 1);
+                else if constexpr (pc == 6) A4_DMA_V(vst, (SLOT + 2) & 3, 2);
+                else A4_DMA_V(vst, (SLOT + 2) & 3, 3);
             }
-            // ---- staging requests: K tile t+4 (pieces 0-3), V tile t+1 (pieces 0-3), in odd gaps of the S half (no LDS
-            // read is being issued there), four gaps apart; such a gap carries nothing else: its share of the softmax
-            // waits for the next odd gap (a request holds the wave for about 37 cycles, more than a gap has to spare)
-            if constexpr (k == 0) src_k = tile_src(t + 4, 0);
-            if constexpr (k == 2) src_v = tile_src(t + 1, 1);
-            if constexpr (a4_is_dma_gap(k)) {
-                constexpr int j = (k - 3) >> 2;
-                if constexpr (j < 4) issue_piece(src_k, t + 4, 0, j); else issue_piece(src_v, t + 1, 1, j - 4);
-            }
-            // ---- softmax share: pair e of the 32 (two scores of S_t per lane); pairs alternate between two register sets
+            if constexpr (k == 14) stage_next(kst, k_row_bytes);      // -> K tile t+5, for the next iteration
+            if constexpr (k == 16) stage_next(vst, v_row_bytes);      // -> V tile t+2, for this one
+            // ---- softmax share: score k of the 64 per lane
             {
-                constexpr int e = k >> 1;
-                if constexpr ((k & 1) == 0) {
-                    constexpr int c = e >> 4, st = (e >> 3) & 1, i0 = 2 * (e & 7);
-                    pv[e & 1][0] = fast_exp2(__builtin_fmaf(scur[c][st][i0], cs, c ? -mc1 : -mc0));
-                    pv[e & 1][1] = fast_exp2(__builtin_fmaf(scur[c][st][i0 + 1], cs, c ? -mc1 : -mc0));
-                } else if constexpr (!a4_is_dma_gap(k)) {
-                    // (the empty asm statements keep the sums and the cast in THIS gap: left alone, the compiler gathers
-                    // them at the end of the iteration and keeps all 64 exponentials alive until then)
-                    auto finish = [&](auto E_) __attribute__((always_inline)) {
-                        constexpr int e2 = decltype(E_)::value, c = e2 >> 4, st = (e2 >> 3) & 1, i0 = 2 * (e2 & 7);
-                        if constexpr (c) { rs1 += pv[e2 & 1][0]; rs1 += pv[e2 & 1][1]; asm volatile("" : "+v"(rs1)); }
-                        else { rs0 += pv[e2 & 1][0]; rs0 += pv[e2 & 1][1]; asm volatile("" : "+v"(rs0)); }
-                        uint32_t pw = a4_pack(pv[e2 & 1][0], pv[e2 & 1][1]);
-                        asm volatile("" : "+v"(pw));
-                        pcur[c][st][i0 >> 3][(i0 & 7) >> 1] = pw;
-                    };
-                    if constexpr (k >= 2 && a4_is_dma_gap(k - 2)) finish(std::integral_constant<int, e - 1>{});   // the pair a request displaced
-                    finish(std::integral_constant<int, e>{});
-                }
+                constexpr int c = k >> 5, st = (k >> 4) & 1, i = k & 15;
+                pv[k & 3] = fast_exp2(__builtin_fmaf(scur[c][st][i], cs, c ? -m_run[1] : -m_run[0]));
+                if constexpr ((k & 1) == 1 && k >= 3) finish(std::integral_constant<int, k - 3>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // the K fragments of the next iteration's S product are in (and no read of this tile's V is outstanding)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bool exact = active && !fast;
-        if (fast) {
-            if (__any(!(rs0 <= OPTIMISTIC_MAX) || !(rs1 <= OPTIMISTIC_MAX))) exact = true;
-            else { l_run[0] += rs0; l_run[1] += rs1; }
+        finish(std::integral_constant<int, 62>{});
+        // (no LDS read is outstanding: the last MFMAs waited for the last V reads, and the K reads came before those)
+        bool exact;
+        if (__builtin_expect(t < t_fast_now, 1)) {
+            float rsm;
+            asm("v_max_f32 %0, %1, %2" : "=v"(rsm) : "v"(rs0), "v"(rs1));
+            exact = __builtin_expect(__any(!(rsm <= OPTIMISTIC_MAX)), 0);
+            if (!exact) { l_run[0] += rs0; l_run[1] += rs1; }
+        } else {
+            exact = (t < my_nkt);
         }
-        if (exact) softmax_exact(scur, pcur, t, need_mask);
-        if (!active) {
+        if (__builtin_expect(exact, 0)) {
+            const int kb0 = t * BN;
+            softmax_exact(scur, pcur, t, (kb0 + BN - 1 > 64 * w + shift) || (kb0 + BN > k_len));
+            t_fast_now = __any(m_run[0] < -1e29f || m_run[1] < -1e29f) ? 0 : t_fast;
+        }
+        if (__builtin_expect(t >= my_nkt, 0)) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -428,24 +476,29 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pcur[c][st][s2][i] = 0u;
+                        for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0" : "+v"(pcur[c][st][s2][i]));
         }
         __builtin_amdgcn_sched_barrier(0);
     };
 
     if (nkt > 0) {
-        // prologue: K tiles 0 .. 3 and V tile 0; S_0 from K tile 0, then the fragments of K tile 1 for iteration 0
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            issue_piece(tile_src(0, 0), 0, 0, j); issue_piece(tile_src(1, 0), 1, 0, j); issue_piece(tile_src(2, 0), 2, 0, j);
-            issue_piece(tile_src(3, 0), 3, 0, j); issue_piece(tile_src(0, 1), 0, 1, j);
+        // prologue: K tiles 0 .. 3 and V tiles 0, 1; S_0 from K tile 0, then the fragments of K tile 1 for iteration 0
+        {
+            Stage k0 = stage_at(kbase, p.k_rs, 0), k1 = stage_at(kbase, p.k_rs, 1), k2 = stage_at(kbase, p.k_rs, 2), k3 = stage_at(kbase, p.k_rs, 3);
+            Stage v0 = stage_at(vbase, p.v_rs, 0);
+            A4_DMA_K(k0, 0, 0); A4_DMA_K(k0, 0, 1); A4_DMA_K(k0, 0, 2); A4_DMA_K(k0, 0, 3);
+            A4_DMA_V(v0, 0, 0); A4_DMA_V(v0, 0, 1); A4_DMA_V(v0, 0, 2); A4_DMA_V(v0, 0, 3);
+            A4_DMA_K(k1, 1, 0); A4_DMA_K(k1, 1, 1); A4_DMA_K(k1, 1, 2); A4_DMA_K(k1, 1, 3);
+            A4_DMA_K(k2, 2, 0); A4_DMA_K(k2, 2, 1); A4_DMA_K(k2, 2, 2); A4_DMA_K(k2, 2, 3);
+            A4_DMA_K(k3, 3, 0); A4_DMA_K(k3, 3, 1); A4_DMA_K(k3, 3, 2); A4_DMA_K(k3, 3, 3);
+            A4_DMA_V(vst, 1, 0); A4_DMA_V(vst, 1, 1); A4_DMA_V(vst, 1, 2); A4_DMA_V(vst, 1, 3);
         }
         // Iteration 0 multiplies P = 0 by the V slot of "tile -1", which nothing has written: zero it (0 x NaN is NaN).
         {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < PPW; ++j)
-                *(LDS_PTR(f32x4, lds0 + VRING + (NVS - 1) * TILEB + (PPW * w + j) * 1024 + lane * 16)) = z;
+                *(LDS_PTR(f32x4, lds0 + (NS - 1) * TILEB + (PPW * w + j) * 1024 + lane * 16)) = z;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define A4_RK(st, ks, off) a4_read_k<a4_K(st, ks), st * 32 * ROWB + off>(k_addr0 ^ (uint32_t)(ks << 5));
@@ -466,13 +519,21 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
 #undef A4_RK
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // iteration t: PV of tile t-1, S of tile t+1, softmax of tile t; one more iteration for the last PV
-        for (int t = 0; t <= nkt; t += 2) {
-            iteration(t, sA, sB, pB, pA);
-            if (t + 1 <= nkt) iteration(t + 1, sB, sA, pA, pB);
+        for (int t = 0;; t += 4) {
+            iteration(std::integral_constant<int, 0>{}, t);
+            if (t + 1 > nkt) break;
+            iteration(std::integral_constant<int, 1>{}, t + 1);
+            if (t + 2 > nkt) break;
+            iteration(std::integral_constant<int, 2>{}, t + 2);
+            if (t + 3 > nkt) break;
+            iteration(std::integral_constant<int, 3>{}, t + 3);
+            if (t + 4 > nkt) break;
         }
         // no staging request may outlive the workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#undef A4_DMA_K
+#undef A4_DMA_V
 
     // ---- epilogue: O^T out of the accumulator half (12 wait states after the last MFMA), normalise, store.
     // The lane's row is re-derived from a lane id the compiler cannot trace back, so that no output address is computed
@@ -509,7 +570,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                     *reinterpret_cast<bf16x4*>(optr + 32 * mt + 8 * g4 + 4 * h_e) = ov;
                 }
             if (h_e == 0) {
-                float lse = (l_tot > 0.f) ? (m_run[c] * p.scale + __logf(l_tot)) : -INFINITY;
+                float lse = (l_tot > 0.f) ? (m_run[c] * 0.6931471805599453f + __logf(l_tot)) : -INFINITY;
                 p.lse[(int64_t)head * p.lse_stride + q_row0 + qi_c] = lse;
             }
         }
@@ -523,7 +584,7 @@ int lv_launch_fwd_a4(const FwdParams& p0, int causal, hipStream_t stream) {
     p.head_per_xcd = lv_head_per_xcd(p) ? 1 : 0;
     dim3 grid(p.head_per_xcd ? (unsigned)(((p.hkv + 7) / 8) * 8 * p.n_blocks * p.group)
                              : (unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8 * p.group)), block(256);
-    size_t lds = (size_t)(4 + 3) * 64 * 128 * 2;   // K ring + V ring
+    size_t lds = (size_t)(4 + 4) * 64 * 128 * 2;   // V ring + K ring
     if (causal) hipLaunchKernelGGL((lv_fwd_a4_kernel<true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((lv_fwd_a4_kernel<false>), grid, block, lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;

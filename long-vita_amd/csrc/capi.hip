@@ -59,8 +59,12 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
     return LV_OK;
 }
 static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
-static bool fwd_a4(int d) { return d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0); }
-static bool fwd_pingpong(int d) { return fwd_kernel_override() == 1; }
+// (the one-wave kernel stages K / V rows at 256-byte granularity: row strides that are not multiples of 128 elements, views
+// no real layout of this path produces, take the ping-pong kernel)
+static bool fwd_a4(int d, int64_t k_rs, int64_t v_rs) {
+    return d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0) && k_rs % 128 == 0 && v_rs % 128 == 0;
+}
+static bool fwd_pingpong(int d) { return fwd_kernel_override() == 1 || (d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0)); }
 // Query rows per forward work item: 256 (8 waves per workgroup); with the lockstep kernel forced,
 // LVATTN_FWD_WAVES=4 selects 128-row items (4 waves, two workgroups per CU).
 // Follows lvattn_select_fwd_kernel: descriptors must be (re)built with the block size in force at launch time.
@@ -211,7 +215,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
     int dense_waves = 8;
     if (dense) {
         if (causal && k_rows_total < q_rows_total) return fail(LV_EINVAL, "lvattn_fwd_dense: causal needs k_rows >= q_rows (%d < %d)", k_rows_total, q_rows_total);
-        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d);
+        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d, k_rs, v_rs);
         if (lockstep) {
             auto slots = [&](int nw) { return (q_rows_total + 32 * nw - 1) / (32 * nw) * nw; };
             if (fwd_waves() == 4 || slots(4) < slots(8)) dense_waves = 4;
@@ -246,7 +250,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
         if (lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
         return LV_OK;
     }
-    const int rc = fwd_a4(d) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
+    const int rc = fwd_a4(d, k_rs, v_rs) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
                    : fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
                    : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
                                      : lv_launch_fwd(p, d, causal, dense ? dense_waves : fwd_waves(), (hipStream_t)stream);

@@ -322,6 +322,28 @@ def test_dense_entry_point_strided_views_and_errors():
         ops.attn_fwd_dense_launch(q[:, :, :32], k[:, :, :32], v[:, :, :32], 0.125, False)     # head dim 32
 
 
+def test_head_dim_128_row_strides_with_and_without_256_byte_granularity():
+    """Head dim 128: q / k / v as views of one packed [rows, (Hq + 2 Hkv) * 128] buffer (row strides that are multiples of
+    128 elements: the default kernel), and as views of a buffer with 8 padding elements per row (strides the default
+    kernel does not take: the launch falls back to the ping-pong kernel).  Both match the oracle."""
+    from long_vita_amd import ops
+    Hq, Hkv, D = 4, 2, 128
+    cu = [0, 300, 301, 1000]
+    width = (Hq + 2 * Hkv) * D
+    for pad in (0, 8):
+        g = torch.Generator().manual_seed(21 + pad)
+        buf = (torch.randn(cu[-1], width + pad, generator=g) * 0.7).to(torch.bfloat16).cuda()
+        q = buf[:, :Hq * D].unflatten(1, (Hq, D))
+        k = buf[:, Hq * D:(Hq + Hkv) * D].unflatten(1, (Hkv, D))
+        v = buf[:, (Hq + Hkv) * D:width].unflatten(1, (Hkv, D))
+        assert k.stride(0) == width + pad and not k.is_contiguous()
+        out, lse = ops.varlen_attention(q, k, v, cu, A.default_scale(D), True)
+        ref_o, ref_lse = A.varlen_attention(q.cpu().contiguous(), k.cpu().contiguous(), v.cpu().contiguous(), cu, A.default_scale(D), True)
+        torch.cuda.synchronize()
+        assert rel_err(out, ref_o) <= REL_TOL, pad
+        assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL, pad
+
+
 def test_full_size_backward_invariants_cfg3():
     """Backward at the 131,072-token / 40-8-head size of the forward+backward measurements, checked through identities
     that hold at any size: rows of P sum to one, so  sum_j dV[j] = sum over the group's heads and all rows of dO;

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Cycles (not wall time: probe builds change the chip's clock) of the forward kernel for a list of library builds.
+# tools_diag/probe_cycles.sh "<lib> ..." [seq]   -- run on the GPU box from the repo root
+LIBS=$1; SEQ=${2:-131072}
+R=$GRAFT_REPO_ROOT
+L=$R/long-vita_amd/liblvattn.so
+cp $L /tmp/lv_orig.so
+export TMPDIR=/tmp
+cd /tmp
+for lib in $LIBS; do
+  [ "$lib" = liblvattn.so ] && cp /tmp/lv_orig.so $L || cp $R/long-vita_amd/$lib $L
+  rm -rf /tmp/pc_out
+  timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc_out --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python3 $R/bench.py --seq $SEQ --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pc.log 2>&1 || { cp /tmp/lv_orig.so $L; tail -5 /tmp/pc.log; exit 1; }
+  python3 - "$lib" <<'PY'
+import csv, glob, sys, collections
+agg = collections.defaultdict(list)
+for f in glob.glob("/tmp/pc_out/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "lv_fwd" in row["Kernel_Name"]:
+            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+dur = []
+for f in glob.glob("/tmp/pc_out/**/*kernel_trace.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "lv_fwd" in row["Kernel_Name"]:
+            dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+g = agg["GRBM_GUI_ACTIVE"]; m = agg["SQ_VALU_MFMA_BUSY_CYCLES"]
+cyc = sum(g) / len(g) / 8
+print(f"{sys.argv[1]:24s} Mcycles/XCD {cyc/1e6:9.2f}  ms {sum(dur)/len(dur):8.3f}  GHz {cyc/(sum(dur)/len(dur))/1e6:5.3f}  mfma_busy {sum(m)/len(m)/1024/cyc:5.3f}")
+PY
+done
+cp /tmp/lv_orig.so $L
