@@ -10,7 +10,7 @@ cd /tmp
 for lib in $LIBS; do
   [ "$lib" = liblvattn.so ] && cp /tmp/lv_orig.so $L || cp $R/long-vita_amd/$lib $L
   rm -rf /tmp/pc_out
-  timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc_out --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- python3 $R/bench.py --seq $SEQ --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pc.log 2>&1 || { cp /tmp/lv_orig.so $L; tail -5 /tmp/pc.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc_out --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES TCC_HIT_sum TCC_MISS_sum -- python3 $R/bench.py --seq $SEQ --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline > /tmp/pc.log 2>&1 || { cp /tmp/lv_orig.so $L; tail -5 /tmp/pc.log; exit 1; }
   python3 - "$lib" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
@@ -25,7 +25,8 @@ for f in glob.glob("/tmp/pc_out/**/*kernel_trace.csv", recursive=True):
             dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
 g = agg["GRBM_GUI_ACTIVE"]; m = agg["SQ_VALU_MFMA_BUSY_CYCLES"]
 cyc = sum(g) / len(g) / 8
-print(f"{sys.argv[1]:24s} Mcycles/XCD {cyc/1e6:9.2f}  ms {sum(dur)/len(dur):8.3f}  GHz {cyc/(sum(dur)/len(dur))/1e6:5.3f}  mfma_busy {sum(m)/len(m)/1024/cyc:5.3f}")
+h = sum(agg["TCC_HIT_sum"]); mi = sum(agg["TCC_MISS_sum"])
+print(f"{sys.argv[1]:24s} Mcycles/XCD {cyc/1e6:9.2f}  ms {sum(dur)/len(dur):8.3f}  GHz {cyc/(sum(dur)/len(dur))/1e6:5.3f}  mfma_busy {sum(m)/len(m)/1024/cyc:5.3f}  L2 hit {h/max(1.0,h+mi):5.3f}")
 PY
 done
 cp /tmp/lv_orig.so $L
