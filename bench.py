@@ -442,6 +442,12 @@ def main():
             res["per_rank"] = per_rank
         try:    # the clock the chip holds under a dense MFMA loop: the peak above assumes 2.4 GHz
             res["mfma_clock_mhz"] = ops.mfma_clock_mhz(dev)
+            if res["roofline"]["bound"] == "mfma":
+                # the same peak at the clock this chip holds under nothing but bf16 MFMAs on random data (its power limit): what
+                # a kernel made of MFMAs alone would reach here; `frac` stays against the nominal 2.4 GHz peak
+                sustained = PEAK_BF16_TFLOPS * res["mfma_clock_mhz"]["median"] / 2400.0
+                res["roofline"]["peak_at_sustained_mfma_clock"] = sustained
+                res["roofline"]["frac_of_sustained"] = res["roofline"]["achieved"] / sustained
         except Exception as e:      # diagnostic only
             res["mfma_clock_mhz"] = {"error": str(e)}
         res["host_cpus"] = os.cpu_count()

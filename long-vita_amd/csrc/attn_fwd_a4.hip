@@ -24,68 +24,13 @@
 // kept short: it is unrolled four times, which makes every ring slot a compile-time constant (LDS addresses are one lane
 // register plus an immediate, staging destinations one scalar add into M0), the staging descriptors are advanced
 // instead of rebuilt, and the per-tile decisions are one scalar compare against a precomputed tile index.
-#include "internal.h"
-#include <type_traits>
-
-typedef __attribute__((address_space(3))) char lds_char;
-typedef __attribute__((ext_vector_type(4))) uint32_t a4_u32x4;
-
-// One staging request: piece J of a tile (1 KiB per wave).  M0 = wave_base + DST (the LDS destination), the lane's
-// global offset is its offset in piece 0 with J XORed into the chunk bits plus J row steps; the address instruction sits
-// in the wait state that the M0 write needs before the request.  M0 is not restored: nothing else here uses it.
-template <int DST, int J>
-__device__ __forceinline__ void a4_dma(a4_u32x4 rs, int voff0, int jstep, uint32_t wave_base) {
-    if constexpr (J == 0) {
-        asm volatile("s_add_i32 m0, %2, %c3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                     :: "v"(voff0), "s"(rs), "s"(wave_base), "i"(DST) : "memory", "scc");
-    } else {
-        int voff;
-        asm volatile("s_add_i32 m0, %4, %c5\n\tv_xad_u32 %0, %1, %c6, %2\n\tbuffer_load_dwordx4 %0, %3, 0 offen lds"
-                     : "=&v"(voff) : "v"(voff0), "s"(jstep), "s"(rs), "s"(wave_base), "i"(DST), "i"(J << 4) : "memory", "scc");
-    }
-}
+#include "a4_asm.h"
 
 // accumulator register numbers
 __device__ constexpr int a4_O(int c, int mt) { return 64 * c + 16 * mt; }
 __device__ constexpr int a4_Q(int c, int ks) { return 128 + 32 * c + 4 * ks; }
 __device__ constexpr int a4_K(int st, int ks) { return 192 + 32 * st + 4 * ks; }
 
-// a[A .. A+3] = one 16-byte fragment held in vector registers
-template <int A>
-__device__ __forceinline__ void a4_put4(a4_u32x4 x) {
-    asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
-                 :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "i"(A), "i"(A + 1), "i"(A + 2), "i"(A + 3));
-}
-template <int A>
-__device__ __forceinline__ void a4_zero16() {
-    asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "i"(A));
-    if constexpr ((A & 15) != 15) a4_zero16<A + 1>();
-}
-template <int A>
-__device__ __forceinline__ float a4_get() {
-    float x;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(A));
-    return x;
-}
-// a[A] *= alpha for 16 consecutive registers (a rare path: the running maximum grew by more than the threshold)
-template <int A, int N>
-__device__ __forceinline__ void a4_scale(float alpha) {
-    float t;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a[%c2], %0"
-                 : "=&v"(t) : "v"(alpha), "i"(A));
-    if constexpr (N > 1) a4_scale<A + 1, N - 1>(alpha);
-}
-// K fragment (st, ks) <- LDS
-template <int A, int OFF>
-__device__ __forceinline__ void a4_read_k(uint32_t lds_addr) {
-    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(lds_addr), "i"(A), "i"(A + 3), "i"(OFF) : "memory");
-}
-// V fragment half <- LDS (transposed 8-byte read).  The destination is a vector register the compiler allocates, but it
-// does not count this read: the MFMA that uses it carries the s_waitcnt with the right count (a4_mfma_o).
-template <int OFF>
-__device__ __forceinline__ void a4_read_v(bf16x4& dst, uint32_t lds_addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
-}
 // LDS reads of one iteration, by gap (each gap: its MFMA first, then its V reads, then its K read).  All sit in even
 // gaps; the odd ones are full with the second half of the softmax share.
 //   K_{t+2} fragment f = (st, ks) in gap 6 + 2 f: the S product is done with that register two gaps earlier at the latest
@@ -106,47 +51,6 @@ __device__ constexpr int a4_v_pending(int k, int mt_last) {
 __device__ constexpr int a4_dma_piece(int k) {   // 0-3: K piece, 4-7: V piece, -1: none
     return (k < 32 && (k & 3) == 3) ? (k >> 2) : -1;
 }
-// S^T tile += K fragment x Q fragment (both in the accumulator half); FIRST: the product starts from zero
-template <int KA, int QA, bool FIRST>
-__device__ __forceinline__ void a4_mfma_s(f32x16& s) {
-    if constexpr (FIRST)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
-    else
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(KA), "i"(KA + 3), "i"(QA), "i"(QA + 3));
-}
-// O^T tile += V fragment x P fragment (vector registers); WAIT >= 0: first let all but WAIT LDS reads land
-template <int OA, int WAIT>
-__device__ __forceinline__ void a4_mfma_o(bf16x8 vf, bf16x8 pf) {
-    if constexpr (WAIT >= 0)
-        asm volatile("s_waitcnt lgkmcnt(%c4)\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"
-                     :: "v"(vf), "v"(pf), "i"(OA), "i"(OA + 15), "i"(WAIT) : "memory");
-    else
-        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf), "v"(pf), "i"(OA), "i"(OA + 15));
-}
-// two fp32 -> one dword of two bf16 (round to nearest even), the first in the low half
-__device__ __forceinline__ uint32_t a4_pack(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-    bf16x2_ v;
-    v[0] = (__bf16)a; v[1] = (__bf16)b;
-    return __builtin_bit_cast(uint32_t, v);
-}
-// The same as a store into a register that already holds a value: on the rare paths (exact pass, tiles past the wave's
-// rows) P is overwritten IN the registers the optimistic pass filled, so that the two paths meet without a copy on the
-// common one.
-__device__ __forceinline__ void a4_pack_into(uint32_t& dst, float a, float b) {
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "+v"(dst) : "v"(a), "v"(b));
-}
-template <int N>
-__device__ __forceinline__ void a4_nop() { asm volatile("s_nop %c0" :: "i"(N - 1)); }
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void a4_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        a4_static_for<I + 1, N>(f);
-    }
-}
-
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     constexpr int D = 128;
@@ -274,8 +178,8 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
         st.rs[2] = (uint32_t)(rows * row_bytes);
     };
     // piece j of K tile -> K slot, of V tile -> V slot (prologue form: slot and piece are compile-time there too)
-#define A4_DMA_K(st_, slot, j) a4_dma<KRING + (slot) * TILEB + (j) * 1024, j>((st_).rs, kvo0, (j) == 1 ? kstep : (j) == 2 ? kstep2 : kstep3, wave_base)
-#define A4_DMA_V(st_, slot, j) a4_dma<(slot) * TILEB + (j) * 1024, j>((st_).rs, vvo0, (j) == 1 ? vstep : (j) == 2 ? vstep2 : vstep3, wave_base)
+#define A4_DMA_K(st_, slot, j) a4_dma<KRING + (slot) * TILEB + (j) * 1024, j, (j) << 4>((st_).rs, kvo0, (j) == 1 ? kstep : (j) == 2 ? kstep2 : kstep3, wave_base)
+#define A4_DMA_V(st_, slot, j) a4_dma<(slot) * TILEB + (j) * 1024, j, (j) << 4>((st_).rs, vvo0, (j) == 1 ? vstep : (j) == 2 ? vstep2 : vstep3, wave_base)
 
     // ---- LDS read addresses in slot 0 of each ring
     // The XOR swizzle acts on address bits 4..7 only and every slot starts on a multiple of 256 bytes, so the address of

@@ -10,7 +10,7 @@ cd /tmp
 for lib in $LIBS; do
   [ "$lib" = liblvattn.so ] && cp /tmp/lv_orig.so $L || cp $R/long-vita_amd/$lib $L
   rm -rf /tmp/pc_out
-  timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc_out --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES TCC_HIT_sum TCC_MISS_sum -- python3 $R/bench.py --seq $SEQ --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline > /tmp/pc.log 2>&1 || { cp /tmp/lv_orig.so $L; tail -5 /tmp/pc.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc_out --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY TCC_HIT_sum TCC_MISS_sum -- python3 $R/bench.py ${BENCH_ARGS:---seq $SEQ} --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline > /tmp/pc.log 2>&1 || { cp /tmp/lv_orig.so $L; tail -5 /tmp/pc.log; exit 1; }
   python3 - "$lib" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
@@ -26,7 +26,9 @@ for f in glob.glob("/tmp/pc_out/**/*kernel_trace.csv", recursive=True):
 g = agg["GRBM_GUI_ACTIVE"]; m = agg["SQ_VALU_MFMA_BUSY_CYCLES"]
 cyc = sum(g) / len(g) / 8
 h = sum(agg["TCC_HIT_sum"]); mi = sum(agg["TCC_MISS_sum"])
-print(f"{sys.argv[1]:24s} Mcycles/XCD {cyc/1e6:9.2f}  ms {sum(dur)/len(dur):8.3f}  GHz {cyc/(sum(dur)/len(dur))/1e6:5.3f}  mfma_busy {sum(m)/len(m)/1024/cyc:5.3f}  L2 hit {h/max(1.0,h+mi):5.3f}")
+wc = max(1.0, sum(agg["SQ_WAVE_CYCLES"])); wi = sum(agg["SQ_WAIT_INST_ANY"]) / wc; wa = sum(agg["SQ_WAIT_ANY"]) / wc; ac = sum(agg["SQ_ACTIVE_INST_ANY"]) / wc
+ms = sum(dur) / len(dur)
+print(f"{sys.argv[1]:24s} Mcycles/XCD {cyc/1e6:9.2f}  ms {ms:8.3f}  GHz {cyc/ms/1e6:5.3f}  mfma_busy {sum(m)/len(m)/1024/cyc:5.3f}  L2 hit {h/max(1.0,h+mi):5.3f}  wait_inst {wi:5.3f} wait_any {wa:5.3f} active {ac:5.3f} launches {len(g)}")
 PY
 done
 cp /tmp/lv_orig.so $L
