@@ -24,8 +24,8 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" int lvattn_abi_version(void) { return 1; }
 
-// Forward kernel choice.  Default: the one-wave-per-SIMD kernel ("a4") for head dim 128 and the lockstep kernel for
-// head dim 64; the ping-pong kernel ("pp") carries the fused rotary embedding and stays selectable, as do pp16 and
+// Forward kernel choice.  Default: the one-wave-per-SIMD kernel ("a4") for head dim 128 (launches of at least 65,536 query
+// rows; smaller ones take "pp") and the lockstep kernel for head dim 64; the ping-pong kernel ("pp") carries the fused rotary embedding and stays selectable, as do pp16 and
 // lockstep (a4 +1.8 % over pp at 1M tokens, pp +13 % over lockstep at d = 128, lockstep +16 % over pp at d = 64).  The
 // environment variable LVATTN_FWD_KERNEL=a4 / pp / pp16 / lockstep forces one (a4 and pp16 exist for d = 128 only:
 // other head dims then take their default).
@@ -60,9 +60,11 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
 }
 static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
 // (the one-wave kernel stages K / V rows at 256-byte granularity: row strides that are not multiples of 128 elements, views
-// no real layout of this path produces, take the ping-pong kernel)
-static bool fwd_a4(int d, int64_t k_rs, int64_t v_rs) {
-    return d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0) && k_rs % 128 == 0 && v_rs % 128 == 0;
+// no real layout of this path produces, take the ping-pong kernel; so do small launches when the choice is the library's:
+// at 8K rows the ping-pong kernel is up to 7 % faster, its prologue is shorter, at 32K still 0.7 %; from 128K rows on a4 leads)
+static bool fwd_a4(int d, int64_t k_rs, int64_t v_rs, int q_rows_total) {
+    const int o = fwd_kernel_override();
+    return d == 128 && (o == 4 || (o == 0 && q_rows_total >= 65536)) && k_rs % 128 == 0 && v_rs % 128 == 0;
 }
 static bool fwd_pingpong(int d) { return fwd_kernel_override() == 1 || (d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0)); }
 // Query rows per forward work item: 256 (8 waves per workgroup); with the lockstep kernel forced,
@@ -215,7 +217,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
     int dense_waves = 8;
     if (dense) {
         if (causal && k_rows_total < q_rows_total) return fail(LV_EINVAL, "lvattn_fwd_dense: causal needs k_rows >= q_rows (%d < %d)", k_rows_total, q_rows_total);
-        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d, k_rs, v_rs);
+        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d, k_rs, v_rs, q_rows_total);
         if (lockstep) {
             auto slots = [&](int nw) { return (q_rows_total + 32 * nw - 1) / (32 * nw) * nw; };
             if (fwd_waves() == 4 || slots(4) < slots(8)) dense_waves = 4;
@@ -250,7 +252,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
         if (lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
         return LV_OK;
     }
-    const int rc = fwd_a4(d, k_rs, v_rs) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
+    const int rc = fwd_a4(d, k_rs, v_rs, q_rows_total) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
                    : fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
                    : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
                                      : lv_launch_fwd(p, d, causal, dense ? dense_waves : fwd_waves(), (hipStream_t)stream);

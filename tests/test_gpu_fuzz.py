@@ -62,3 +62,29 @@ def test_random_packing_forward_backward(seed):
     assert _rel(qc.grad, rdq) <= REL_TOL, tag
     assert _rel(kc.grad, rdk) <= REL_TOL, tag
     assert _rel(vc.grad, rdv) <= REL_TOL, tag
+
+
+@pytest.mark.parametrize("seed", [s for s in range(40) if _case(s)[0] == 128])
+def test_random_packing_forward_one_wave_kernel(seed):
+    """The same ragged cases at head dim 128 with the one-wave-per-SIMD forward kernel forced: launches this small take the
+    ping-pong kernel when the choice is the library's, so the kernel that serves long contexts is exercised on empty,
+    one-token and block-straddling segments here."""
+    from long_vita_amd import ops, _lib
+    D, Hkv, Hq, causal, cu = _case(seed)
+    T = cu[-1]
+    g = torch.Generator().manual_seed(1000 + seed)
+    q = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(T, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(T, Hkv, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    ref_o, ref_lse = A.varlen_attention(q, k, v, cu, scale, causal)
+    _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"a4"), "select")
+    try:
+        with torch.no_grad():
+            out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), cu, scale, causal)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
+    tag = f"Hq={Hq} Hkv={Hkv} causal={causal} cu={cu}"
+    assert _rel(out, ref_o) <= REL_TOL, tag
+    assert np.abs(lse.detach().cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL, tag
