@@ -1,4 +1,5 @@
-// Flash-style attention forward for gfx950, "one wave per SIMD" form (head dim 128; LVATTN_FWD_KERNEL=a4).
+// Flash-style attention forward for gfx950, "one wave per SIMD" form (head dim 128; the default for long launches,
+// LVATTN_FWD_KERNEL=a4 forces it).
 //
 // One workgroup = 4 waves = one 256-row query block of one query head.  A wave owns 64 query rows (two 32-row column
 // blocks c = 0, 1 of S^T = K Q^T, query row on the lane) and the WHOLE 512-register file of its SIMD, laid out by hand:
@@ -10,8 +11,9 @@
 // (one per column block): half the LDS read bytes per MFMA of the 8-wave kernels, and no partner wave or second
 // barrier per tile.  The compiler neither counts nor pads what is inside an asm statement: the waits and the wait
 // states (a vector write -> MFMA operand: 2; an MFMA result -> any other reader: 12) are written out here.
-// The build must show no compiler v_accvgpr_* and no spill (the vector half has to stay within 256 registers); see
-// the top of the kernel for how the accumulator half is kept out of the register allocator's hands.
+// The build must show no compiler v_accvgpr_* and no spill (the vector half has to stay within 256 registers): the
+// Makefile runs audit_a4.py over this file's assembly; see the top of the kernel for how the accumulator half is kept
+// out of the register allocator's hands.
 //
 // The loop is software-pipelined: iteration t holds O^T += V_{t-1}^T P_{t-1}^T, S_{t+1}^T = K_{t+1} Q^T and the softmax of
 // S_t, the vector work spread over the 64 MFMA gaps of the iteration; one workgroup barrier per 64-key tile.
