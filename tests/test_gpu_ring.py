@@ -19,8 +19,18 @@ def rel(got, ref):
     return float(np.abs(g - ref).max() / np.abs(ref).max())
 
 
+@pytest.fixture(params=["default", "a4"])
+def forward_kernel(request):
+    """Ring blocks this small take the ping-pong forward kernel when the choice is the library's; "a4" forces the
+    one-wave kernel that serves the long-context ring steps, so its rectangular and half-chunk blocks are checked here."""
+    from long_vita_amd import _lib
+    _lib.check(_lib.lib().lvattn_select_fwd_kernel(request.param.encode()), "select")
+    yield request.param
+    _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
+
+
 @pytest.mark.parametrize("cp,S", [(2, 1024), (4, 2048), (8, 4096)])
-def test_ring_hip_backend_matches_full_causal(cp, S):
+def test_ring_hip_backend_matches_full_causal(cp, S, forward_kernel):
     from long_vita_amd.ring_context_parallel import RingAttention
     Hq, Hkv, D = 10, 2, 128
     g = torch.Generator().manual_seed(cp)
@@ -228,7 +238,7 @@ def test_full_size_ring_rank_equals_single_launch_1m():
 
 
 @pytest.mark.parametrize("cp,cu", [(2, [0, 300, 301, 1500, 2048]), (4, [0, 700, 2100, 2101, 3900, 4096]), (8, [0, 4096])])
-def test_ring_hip_backend_packed_segments(cp, cu):
+def test_ring_hip_backend_packed_segments(cp, cu, forward_kernel):
     """Packed segments under the zig-zag split through the HIP kernels (several rectangles per launch, one launch
     per chunk pair), forward and backward, against the oracle's varlen attention on the whole sequence."""
     from long_vita_amd.ring_context_parallel import RingAttention
