@@ -113,6 +113,22 @@ int lvattn_fwd_dense(const void* q, const void* k, const void* v, void* out, flo
                      int64_t o_row_stride, int64_t o_head_stride,
                      int64_t lse_stride, float softmax_scale, int causal, void* stream);
 
+/* lvattn_fwd with the caller's knowledge of the work items: mean_keys_per_item = keys swept per descriptor on average
+ * (lv_mean_keys_per_item over the host copy of the table; < 0 = unknown, which makes this lvattn_fwd).  Same call sites as
+ * lvattn_fwd; the figure only steers the choice between the two head-dim-128 forward kernels (long sweeps: one wave per
+ * SIMD; short ones, as in a launch of many short packed segments at dot_product_attention.py:352-365: the ping-pong
+ * kernel, 5-20 % faster there), never the result beyond the kernels' rounding. */
+int lvattn_fwd_hinted(const void* q, const void* k, const void* v, void* out, float* lse,
+                      const int32_t* desc_dev, int n_blocks,
+                      int q_rows_total, int k_rows_total, int hq, int hkv, int d,
+                      int64_t q_row_stride, int64_t q_head_stride,
+                      int64_t k_row_stride, int64_t k_head_stride,
+                      int64_t v_row_stride, int64_t v_head_stride,
+                      int64_t o_row_stride, int64_t o_head_stride,
+                      int64_t lse_stride, float softmax_scale, int causal, int mean_keys_per_item, void* stream);
+/* Host side, pure CPU: the mean key count per descriptor of a table the builders above wrote (-1 for an empty table). */
+int lv_mean_keys_per_item(const int32_t* desc_host, int n_blocks);
+
 /* Tuning / test hook, no counterpart in the reference: choose the forward kernel for later lvattn_fwd calls of this
  * process ("default", "a4", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
  * is read on first use otherwise).  Not thread-safe against concurrent launches. */

@@ -31,6 +31,9 @@ _SIGNATURES = {
     "lv_build_bwd_blocks_rect": (_int, [_int, _int, _int, _int, _int, _int, _i32p, _int]),
     "lvattn_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
                           _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _vp]),
+    "lvattn_fwd_hinted": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
+                                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _int, _vp]),
+    "lv_mean_keys_per_item": (_int, [_i32p, _int]),
     "lvattn_fwd_dense": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _int, _vp]),
     "lvattn_bwd_delta": (_int, [_vp, _vp, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _i64, _vp]),

@@ -60,11 +60,20 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
 }
 static bool fwd_pp16(int d) { return d == 128 && fwd_kernel_override() == 3; }
 // (the one-wave kernel stages K / V rows at 256-byte granularity: row strides that are not multiples of 128 elements, views
-// no real layout of this path produces, take the ping-pong kernel; so do small launches when the choice is the library's:
-// at 8K rows the ping-pong kernel is up to 7 % faster, its prologue is shorter, at 32K still 0.7 %; from 128K rows on a4 leads)
-static bool fwd_a4(int d, int64_t k_rs, int64_t v_rs, int q_rows_total) {
+// no real layout of this path produces, take the ping-pong kernel.  When the choice is the library's, what decides is the key
+// sweep of a work item: one wave per SIMD leaves a workgroup's prologue uncovered, so short sweeps take the ping-pong kernel.
+// Same-box A/B at 131,072 packed tokens, equal segments: 1K-token segments a4 21 % slower, 8K 8 %, 32K 0.9 %, 64K (mean sweep
+// 32K keys) a4 0.6 % faster; single segments the same: 8K rows 7 % slower, 32K 0.7 %, 128K 0.5 % faster.  `mean_keys` is the
+// caller's figure (lv_mean_keys_per_item over the descriptors it built); without one a causal launch is taken for ONE
+// segment (mean sweep = half the rows), which is what a packed launch through plain lvattn_fwd is then mistaken for)
+static const int kA4MinSweep = 32768;
+static bool fwd_a4(int d, int64_t k_rs, int64_t v_rs, int q_rows_total, int k_rows_total, int causal, int mean_keys) {
     const int o = fwd_kernel_override();
-    return d == 128 && (o == 4 || (o == 0 && q_rows_total >= 65536)) && k_rs % 128 == 0 && v_rs % 128 == 0;
+    if (d != 128 || k_rs % 128 || v_rs % 128) return false;
+    if (o == 4) return true;
+    if (o != 0) return false;
+    if (mean_keys >= 0) return mean_keys >= kA4MinSweep;
+    return causal ? q_rows_total >= 2 * kA4MinSweep : k_rows_total >= kA4MinSweep;
 }
 static bool fwd_pingpong(int d) { return fwd_kernel_override() == 1 || (d == 128 && (fwd_kernel_override() == 4 || fwd_kernel_override() == 0)); }
 // Query rows per forward work item: 256 (8 waves per workgroup); with the lockstep kernel forced,
@@ -202,7 +211,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
                     int hq, int hkv, int d,
                     int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
                     int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream, const RopeArgs* rope,
-                    bool dense = false) {
+                    bool dense = false, int mean_keys = -1) {
     if (int e = check_common(q, k, v, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
     if (!out || !lse || (!desc_dev && !dense)) return fail(LV_EINVAL, "null out/lse/desc pointer");
     if (((uintptr_t)out & 7) || (o_rs & 3) || (o_hs & 3)) return fail(LV_EINVAL, "out must be 8-byte aligned with strides % 4 == 0");
@@ -217,7 +226,9 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
     int dense_waves = 8;
     if (dense) {
         if (causal && k_rows_total < q_rows_total) return fail(LV_EINVAL, "lvattn_fwd_dense: causal needs k_rows >= q_rows (%d < %d)", k_rows_total, q_rows_total);
-        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d, k_rs, v_rs, q_rows_total);
+        // one dense segment: the sweep is known (causal: the rows see k_rows - q_rows + 1 ... k_rows keys)
+        mean_keys = causal ? k_rows_total - q_rows_total / 2 : k_rows_total;
+        const bool lockstep = !fwd_pp16(d) && !fwd_pingpong(d) && !fwd_a4(d, k_rs, v_rs, q_rows_total, k_rows_total, causal, mean_keys);
         if (lockstep) {
             auto slots = [&](int nw) { return (q_rows_total + 32 * nw - 1) / (32 * nw) * nw; };
             if (fwd_waves() == 4 || slots(4) < slots(8)) dense_waves = 4;
@@ -252,7 +263,7 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
         if (lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
         return LV_OK;
     }
-    const int rc = fwd_a4(d, k_rs, v_rs, q_rows_total) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
+    const int rc = fwd_a4(d, k_rs, v_rs, q_rows_total, k_rows_total, causal, mean_keys) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)
                    : fwd_pp16(d) ? lv_launch_fwd_pp16(p, causal, (hipStream_t)stream)
                    : fwd_pingpong(d) ? lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)
                                      : lv_launch_fwd(p, d, causal, dense ? dense_waves : fwd_waves(), (hipStream_t)stream);
@@ -275,6 +286,23 @@ extern "C" int lvattn_fwd_dense(const void* q, const void* k, const void* v, voi
                                 int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, void* stream) {
     return fwd_impl(q, k, v, out, lse, nullptr, 0, q_rows, k_rows, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs,
                     o_rs, o_hs, lse_stride, scale, causal, stream, nullptr, true);
+}
+
+extern "C" int lvattn_fwd_hinted(const void* q, const void* k, const void* v, void* out, float* lse,
+                                 const int32_t* desc_dev, int n_blocks, int q_rows_total, int k_rows_total,
+                                 int hq, int hkv, int d,
+                                 int64_t q_rs, int64_t q_hs, int64_t k_rs, int64_t k_hs, int64_t v_rs, int64_t v_hs,
+                                 int64_t o_rs, int64_t o_hs, int64_t lse_stride, float scale, int causal, int mean_keys_per_item,
+                                 void* stream) {
+    return fwd_impl(q, k, v, out, lse, desc_dev, n_blocks, q_rows_total, k_rows_total, hq, hkv, d, q_rs, q_hs, k_rs, k_hs, v_rs, v_hs,
+                    o_rs, o_hs, lse_stride, scale, causal, stream, nullptr, false, mean_keys_per_item < 0 ? -1 : mean_keys_per_item);
+}
+
+extern "C" int lv_mean_keys_per_item(const int32_t* desc_host, int n_blocks) {
+    if (!desc_host || n_blocks <= 0) return -1;
+    int64_t keys = 0;
+    for (int i = 0; i < n_blocks; ++i) keys += std::max<int32_t>(0, desc_host[(size_t)i * LV_DESC_INTS + 3]);
+    return (int)(keys / n_blocks);
 }
 
 extern "C" int lvattn_fwd_rope(const void* q, const void* k, const void* v, void* out, float* lse,

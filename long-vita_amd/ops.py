@@ -104,15 +104,24 @@ def _block_rows(backward: bool) -> int:
     return LV_BWD_BLOCK_N if backward else _lib.lib().lvattn_fwd_block_m()
 
 
+def _to_device(desc_host: np.ndarray, device) -> torch.Tensor:
+    """Device copy of a descriptor table.  It carries the table's mean key count per work item (``lv_mean_keys``), which
+    the forward launch hands to the library: the choice between the two head-dim-128 forward kernels follows the length
+    of a work item's key sweep, and the library cannot read the table once it is in device memory."""
+    desc_host = np.ascontiguousarray(desc_host)
+    t = torch.from_numpy(desc_host).to(device)
+    t.lv_mean_keys = int(_lib.lib().lv_mean_keys_per_item(desc_host.ctypes.data_as(_I32P), desc_host.shape[0]))
+    return t
+
+
 def blocks_on_device(cu_seqlens: Sequence[int], causal: bool, backward: bool, device) -> torch.Tensor:
     key = ("seg", tuple(int(x) for x in cu_seqlens), bool(causal), bool(backward), str(device), _block_rows(backward))
-    return _blocks.get(key, lambda: torch.from_numpy(build_blocks_host(cu_seqlens, causal, backward)).to(device))
+    return _blocks.get(key, lambda: _to_device(build_blocks_host(cu_seqlens, causal, backward), device))
 
 
 def rect_blocks_on_device(q_row0, q_len, k_row0, k_len, causal, shift, backward, device) -> torch.Tensor:
     key = ("rect", q_row0, q_len, k_row0, k_len, bool(causal), shift, bool(backward), str(device), _block_rows(backward))
-    return _blocks.get(key, lambda: torch.from_numpy(
-        build_rect_blocks_host(q_row0, q_len, k_row0, k_len, causal, shift, backward)).to(device))
+    return _blocks.get(key, lambda: _to_device(build_rect_blocks_host(q_row0, q_len, k_row0, k_len, causal, shift, backward), device))
 
 
 def rects_blocks_on_device(rects, backward: bool, device) -> torch.Tensor:
@@ -127,7 +136,7 @@ def rects_blocks_on_device(rects, backward: bool, device) -> torch.Tensor:
         parts = [build_rect_blocks_host(q0, ql, k0, kl, True, sh, backward) for q0, ql, k0, kl, sh in rects]
         d = np.concatenate(parts) if parts else np.zeros((0, LV_DESC_INTS), dtype=np.int32)
         order = np.argsort(-(d[:, 1].astype(np.int64) * d[:, 3].astype(np.int64)), kind="stable")
-        return torch.from_numpy(np.ascontiguousarray(d[order])).to(device)
+        return _to_device(d[order], device)
     return _blocks.get(key, build)
 
 
@@ -156,11 +165,12 @@ def attn_fwd_launch(q, k, v, desc: torch.Tensor, scale: float, causal: bool, out
         out = torch.empty((rq, hq, d), dtype=torch.bfloat16, device=q.device)
     if lse is None:
         lse = torch.empty((hq, rq), dtype=torch.float32, device=q.device)
-    check(_lib.lib().lvattn_fwd(
+    check(_lib.lib().lvattn_fwd_hinted(
         _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(desc), desc.shape[0],
         rq, rk, hq, hkv, d,
         q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-        out.stride(0), out.stride(1), lse.stride(0), float(scale), int(causal), _stream()), "lvattn_fwd")
+        out.stride(0), out.stride(1), lse.stride(0), float(scale), int(causal), int(getattr(desc, "lv_mean_keys", -1)),
+        _stream()), "lvattn_fwd")
     return out, lse
 
 

@@ -52,6 +52,22 @@ def test_forward_blocks_cover_segments_exactly():
         assert (k0, kl) == (cu[seg], cu[seg + 1] - cu[seg])
 
 
+def test_mean_keys_per_item_of_a_table():
+    """The figure the forward launch hands to the library (lvattn_fwd_hinted): keys swept per descriptor on average."""
+    from long_vita_amd import _lib
+    L = _lib.lib()
+    I32P = C.POINTER(C.c_int32)
+    one = _blocks([0, 131072], True)                       # one causal segment: block b sweeps 256 (b + 1) keys
+    assert L.lv_mean_keys_per_item(one.ctypes.data_as(I32P), one.shape[0]) == int(one[:, 3].astype(np.int64).mean()) == 65664
+    packed = _blocks(list(range(0, 131073, 8192)), True)   # sixteen 8K segments: 128.5 x 32 keys on average
+    assert L.lv_mean_keys_per_item(packed.ctypes.data_as(I32P), packed.shape[0]) == 4224
+    assert L.lv_mean_keys_per_item(packed.ctypes.data_as(I32P), 0) == -1
+    assert L.lv_mean_keys_per_item(None, 4) == -1
+    # the hinted launch validates like the plain one, before any HIP call
+    rc = L.lvattn_fwd_hinted(None, None, None, None, None, None, 1, 1, 1, 1, 1, 128, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1.0, 1, 4224, None)
+    assert rc == -1 and b"null" in L.lvattn_last_error()
+
+
 def test_backward_blocks_visibility_rule():
     cu = [0, 130, 700]
     d = _blocks(cu, True, backward=True)

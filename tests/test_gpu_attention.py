@@ -278,6 +278,38 @@ def test_every_forward_kernel_variant(kernel):
         _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"no-such-kernel"), "select")
 
 
+def test_default_forward_kernel_follows_the_key_sweep():
+    """Head dim 128, the library's own choice: a launch of many short packed segments runs the ping-pong kernel and a
+    long single segment the one-wave kernel, whatever the launch's total row count (the descriptors' mean key count
+    per work item goes to lvattn_fwd_hinted); each result equals, bit for bit, the one of the kernel forced by name."""
+    from long_vita_amd import ops, _lib
+    T, D = 131072, 128
+    q, k, v = (t.cuda() for t in make_qkv(T, 2, 1, D, seed=77))
+    scale = A.default_scale(D)
+
+    def run(cu, kernel):
+        _lib.check(_lib.lib().lvattn_select_fwd_kernel(kernel.encode()), "select")
+        try:
+            out, lse = ops.attn_fwd_launch(q, k, v, ops.blocks_on_device(cu, True, False, "cuda"), scale, True)
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
+        return out, lse
+    packed, single = list(range(0, T + 1, 8192)), [0, T]
+    assert ops.blocks_on_device(packed, True, False, "cuda").lv_mean_keys == 4224
+    assert ops.blocks_on_device(single, True, False, "cuda").lv_mean_keys == 65664
+    for cu, expected in ((packed, "pp"), (single, "a4")):
+        out, lse = run(cu, "default")
+        ref_out, ref_lse = run(cu, expected)
+        assert torch.equal(out, ref_out) and torch.equal(lse, ref_lse), expected
+    # and the packed result is right: rows of the last segment against the oracle
+    out, lse = run(packed, "default")
+    lo = T - 8192
+    ro, rl = A.varlen_attention(q[lo:].cpu(), k[lo:].cpu(), v[lo:].cpu(), [0, 8192], scale, True)
+    assert rel_err(out[lo:], ro) <= REL_TOL
+    assert np.abs(lse[:, lo:].cpu().numpy().astype(np.float64) - rl).max() <= LSE_TOL
+
+
 @pytest.mark.parametrize("rows,k_rows,Hq,Hkv,D,causal", [
     (1025, 1025, 32, 32, 64, False),      # the vision tower's shape: 8 x 128 rows + 1 (4-wave workgroups)
     (1024, 1024, 16, 16, 64, False),      # no rows past the last full item (8-wave workgroups)
