@@ -75,6 +75,16 @@ def dist_setup(n):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        # Establish the ring's point-to-point channels before anything is timed (RCCL sets a pair's channel up on its
+        # first send / recv, which would otherwise land in the first step when the run has no warm-up step).
+        dev = torch.device("cuda", local)
+        token, got = torch.full((8,), float(rank), device=dev), torch.empty((8,), device=dev)
+        ops_ = [dist.P2POp(dist.isend, token, (rank + 1) % world), dist.P2POp(dist.irecv, got, (rank - 1) % world)]
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+        torch.cuda.synchronize()
+        if int(got[0].item()) != (rank - 1) % world:
+            raise SystemExit(f"rank {rank}: ring neighbour check failed (got {got[0].item()})")
     return rank, world, local
 
 

@@ -42,7 +42,7 @@ for seg in (1024, 2048, 4096, 8192, 16384, 32768, 65536):
 for name, cu in packings.items():
     res = {}
     for rnd in range(3):
-        for kern in ("a4", "pp", "default"):
+        for kern in ("a4", "pp", "default", "lockstep"):
             _lib.check(_lib.lib().lvattn_select_fwd_kernel(kern.encode()), "select")
             desc = ops.blocks_on_device(cu, True, False, dev)
             ops.attn_fwd_launch(q, k, v, desc, scale, True, out, lse)
@@ -57,5 +57,5 @@ for name, cu in packings.items():
     flops = sum(2.0 * D * HQ * L * L for L in lens)
     a4, pp, df = min(res["a4"]), min(res["pp"]), min(res["default"])
     print(f"{name:28s} segs={len(lens):4d} a4 {a4:8.3f} ms ({flops / a4 / 1e9:7.1f} TF)  pp {pp:8.3f} ms ({flops / pp / 1e9:7.1f} TF)  a4/pp {a4 / pp:.3f}"
-          f"  library's choice {df:8.3f} ms", flush=True)
+          f"  library choice {df:8.3f} ms  lockstep {min(res['lockstep']):8.3f} ms", flush=True)
 _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
