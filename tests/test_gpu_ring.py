@@ -115,6 +115,22 @@ def test_ring_two_processes_one_gpu_torch_distributed(tmp_path):
         assert rel(got, ref) <= REL_TOL, name
 
 
+def test_transport_on_the_rccl_backend_one_rank():
+    """The shipped transport class on the REAL RCCL backend (process group "nccl"): one rank posts the grouped
+    isend + irecv of a K/V block to and from itself on the side stream while the block kernel runs on the compute
+    stream, hands completion over as an event, and the received copy gives bit-identical attention; plus the
+    collectives bench.py --gpus N calls (barrier, all_reduce MAX, all_gather_object) and the ring engine on that group.
+    Two ranks on one device are refused by RCCL, so more than one rank runs over gloo in the tests above; this one is what
+    can be said about the RCCL calls themselves on a one-GPU box.  Runs in a process of its own (tests/rccl_one_rank.py)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(36500 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank.py")
+    res = subprocess.run([sys.executable, "-u", script], env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0 and "rccl self-exchange ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
 def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len):
     """One CP rank of the entry-point test: ambient state as Megatron / MindSpeed would hold it, the batch cut by
     get_batch_on_this_cp_rank, attention through flash_attention_forward, results reassembled by sync_output."""
