@@ -232,6 +232,13 @@ int lvattn_merge_init(float* out_acc, float* lse_acc, const void* out_blk, const
  * the remaining side*side tokens form a square grid; out [n, (side/2)^2, 4c]. */
 int lv_pixel_shuffle(const void* in, void* out, int n, int side, int c, int skip,
                      int64_t in_image_stride, void* stream);
+/* lv_pixel_shuffle_v2: the other token compression of MegatronVisionModel.forward_once, taken with
+ * --vision-downsample-stride (lcvlm_modellink/pretrain_lcvlm.py:472-476, pixel_shuffle_v2 :558-570): every
+ * scale_stride x scale_stride patch of the side x side token grid becomes one token of scale_stride^2 * c channels, the
+ * patch's tokens in (row, column) order, zeros where a patch hangs over the right / bottom edge.  in as for
+ * lv_pixel_shuffle (the first `skip` tokens of an image dropped); out [n, ceil(side/scale_stride)^2, scale_stride^2 * c]. */
+int lv_pixel_shuffle_v2(const void* in, void* out, int n, int side, int c, int skip, int scale_stride,
+                        int64_t in_image_stride, void* stream);
 /* lv_scatter_rows: LanguageModelEmbedding.forward visual-feature scatter
  * (lcvlm_modellink/core/models/common/embeddings/language_model_embedding.py:123,131):
  * dst[dst_index[i]] = src[src_index[i]] for i < n, rows of `width` bf16 elements

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "lvattn_merge_init": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _i64, _vp]),
     "lv_clock_probe": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
     "lv_pixel_shuffle": (_int, [_vp, _vp, _int, _int, _int, _int, _i64, _vp]),
+    "lv_pixel_shuffle_v2": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _i64, _vp]),
     "lv_scatter_rows": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _i64, _vp]),
     "lv_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "lvattn_select_fwd_kernel": (_int, [C.c_char_p]),

@@ -620,6 +620,49 @@ extern "C" int lv_pixel_shuffle(const void* in, void* out, int n, int side, int 
 }
 
 // ---------------------------------------------------------------------------
+// pixel shuffle, stride form (pixel_shuffle_v2): every st x st patch of the token grid becomes ONE output token whose
+// channels are the patch's tokens in (row, column) order,
+//   out[n][a * ceil(side/st) + b][ (di*st + dj)*c + ch ] = in[n][a*st + di][b*st + dj][ch]
+// with zeros where the patch hangs over the edge of the grid (the reference pads right and bottom).  One thread per
+// 16 bytes of output.
+// ---------------------------------------------------------------------------
+__global__ void lv_pixel_shuffle_v2_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int n, int side, int c,
+                                           int skip, int st, int64_t in_image_stride) {
+    const int cpr = c / 8;
+    const int os = (side + st - 1) / st;
+    const int64_t total = (int64_t)n * os * os * st * st * cpr;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % cpr);
+        int64_t t = idx / cpr;
+        const int dj = (int)(t % st); t /= st;
+        const int di = (int)(t % st); t /= st;
+        const int b = (int)(t % os); t /= os;
+        const int a = (int)(t % os);
+        const int img = (int)(t / os);
+        const int i = a * st + di, j = b * st + dj;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (i < side && j < side)
+            val = *reinterpret_cast<const u32x4*>(in + (int64_t)img * in_image_stride + ((int64_t)(skip + i * side + j)) * c + ch * 8);
+        *reinterpret_cast<u32x4*>(out + idx * 8) = val;
+    }
+}
+
+extern "C" int lv_pixel_shuffle_v2(const void* in, void* out, int n, int side, int c, int skip, int scale_stride,
+                                   int64_t in_image_stride, void* stream) {
+    if (!in || !out) return fail(LV_EINVAL, "null pointer");
+    if (side <= 0 || scale_stride <= 0 || c <= 0 || c % 8 || n < 0 || skip < 0) return fail(LV_EINVAL, "lv_pixel_shuffle_v2: bad shape (c %% 8 == 0, stride > 0)");
+    if ((in_image_stride & 7) || (((uintptr_t)in | (uintptr_t)out) & 15)) return fail(LV_EINVAL, "bad alignment");
+    if (((int64_t)skip * c) & 7) return fail(LV_EINVAL, "skip*c must be a multiple of 8");
+    if (n == 0) return LV_OK;
+    const int os = (side + scale_stride - 1) / scale_stride;
+    const int64_t total = (int64_t)n * os * os * scale_stride * scale_stride * (c / 8);
+    int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(lv_pixel_shuffle_v2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)in, (__bf16*)out, n, side, c,
+                       skip, scale_stride, in_image_stride);
+    return hipGetLastError() == hipSuccess ? LV_OK : fail(LV_ELAUNCH, "pixel_shuffle_v2 launch failed");
+}
+
+// ---------------------------------------------------------------------------
 // row scatter / gather (16-byte or 4-byte granules)
 // ---------------------------------------------------------------------------
 template <typename VEC>

@@ -361,6 +361,51 @@ def pixel_shuffle_tokens_launch(vit_output: torch.Tensor, skip: int = 1) -> torc
     return out
 
 
+class _PixelShuffleV2Tokens(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vit_output, skip, scale_stride):
+        ctx.skip, ctx.st, ctx.in_shape = skip, scale_stride, vit_output.shape
+        return pixel_shuffle_v2_tokens_launch(vit_output, skip, scale_stride)
+
+    @staticmethod
+    def backward(ctx, dy):      # every input token went to exactly one place: read it back from there (the padding has no source)
+        n, t, c = ctx.in_shape
+        st = ctx.st
+        side = int(round(math.sqrt(t - ctx.skip)))
+        os_ = (side + st - 1) // st
+        g = dy.reshape(n, os_, os_, st, st, c).permute(0, 1, 3, 2, 4, 5).reshape(n, os_ * st, os_ * st, c)
+        dx = torch.zeros(ctx.in_shape, dtype=dy.dtype, device=dy.device)
+        dx[:, ctx.skip:] = g[:, :side, :side].reshape(n, side * side, c)
+        return dx, None, None
+
+
+def pixel_shuffle_v2_tokens(vit_output: torch.Tensor, skip: int = 1, scale_stride: int = 2) -> torch.Tensor:
+    """Differentiable form of ``pixel_shuffle_v2_tokens_launch``."""
+    if torch.is_grad_enabled() and vit_output.requires_grad:
+        return _PixelShuffleV2Tokens.apply(vit_output, skip, scale_stride)
+    return pixel_shuffle_v2_tokens_launch(vit_output, skip, scale_stride)
+
+
+def pixel_shuffle_v2_tokens_launch(vit_output: torch.Tensor, skip: int = 1, scale_stride: int = 2) -> torch.Tensor:
+    """[N, skip + side*side, C] bf16 -> [N, ceil(side/st)^2, st*st*C]: class-token drop + the stride form of the token
+    compression (lcvlm_modellink/pretrain_lcvlm.py:472-476, 558-570; zero padding on the right / bottom of an odd grid)."""
+    _require_gpu(vit_output)
+    if vit_output.dtype != torch.bfloat16:
+        raise LvAttnError("pixel_shuffle_v2_tokens expects bfloat16")
+    if int(scale_stride) < 1:
+        raise LvAttnError("scale_stride must be a positive integer")
+    x = vit_output if (vit_output.stride(2) == 1 and vit_output.stride(1) == vit_output.shape[2]) else vit_output.contiguous()
+    n, t, c = x.shape
+    side = int(round(math.sqrt(t - skip)))
+    if side * side != t - skip:
+        raise LvAttnError(f"{t - skip} tokens do not form a square grid")
+    st = int(scale_stride)
+    os_ = (side + st - 1) // st
+    out = torch.empty((n, os_ * os_, st * st * c), dtype=x.dtype, device=x.device)
+    check(_lib.lib().lv_pixel_shuffle_v2(_ptr(x), _ptr(out), n, side, c, skip, st, x.stride(0), _stream()), "lv_pixel_shuffle_v2")
+    return out
+
+
 def scatter_rows_(dst: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor, src_index: torch.Tensor | None = None):
     """dst[dst_index[i]] = src[src_index[i]] over 2-D row views (bf16, contiguous rows); a raw launch, no autograd:
     it refuses tensors that are part of a graph (use ``scatter_rows`` for those)."""

@@ -1,6 +1,7 @@
 """Vision-token compression and the scatter of visual features into the LLM input.
 
   pixel_shuffle / vit_output_to_llm_tokens   lcvlm_modellink/pretrain_lcvlm.py:463-470, 546-556
+  pixel_shuffle_v2                           the stride form, pretrain_lcvlm.py:472-476, 558-570
   scatter_external_features                  lcvlm_modellink/core/models/common/embeddings/
                                              language_model_embedding.py:114-134
   vit_attention                              the InternViT-300M core attention call
@@ -32,10 +33,21 @@ def pixel_shuffle(x: torch.Tensor, scale_factor: float = 0.5) -> torch.Tensor:
     return out.reshape(n, w // 2, h // 2, 4 * c)
 
 
-def vit_output_to_llm_tokens(vit_output: torch.Tensor, add_class_token: bool = True) -> torch.Tensor:
+def pixel_shuffle_v2(x: torch.Tensor, scale_stride: int = 2) -> torch.Tensor:
+    """[N, W, H, C] (W == H) -> [N, ceil(W/s) * ceil(H/s), s*s*C]: every s x s patch of the grid becomes one token, zeros
+    where a patch hangs over the right / bottom edge (pretrain_lcvlm.py:558-570)."""
+    n, w, h, c = x.shape
+    assert w == h
+    return ops.pixel_shuffle_v2_tokens(x.reshape(n, w * h, c), skip=0, scale_stride=int(scale_stride))
+
+
+def vit_output_to_llm_tokens(vit_output: torch.Tensor, add_class_token: bool = True, scale_stride: int = 1) -> torch.Tensor:
     """[N, 1025, C] -> [N, 256, 4C]: class-token drop + reshape + pixel_shuffle(0.5) + flatten,
-    fused into one pass over the data."""
-    return ops.pixel_shuffle_tokens(vit_output, skip=1 if add_class_token else 0)
+    fused into one pass over the data; with ``scale_stride`` > 1 the stride form (pixel_shuffle_v2) instead."""
+    skip = 1 if add_class_token else 0
+    if scale_stride != 1:
+        return ops.pixel_shuffle_v2_tokens(vit_output, skip=skip, scale_stride=int(scale_stride))
+    return ops.pixel_shuffle_tokens(vit_output, skip=skip)
 
 
 def scatter_external_features(word_embeddings: torch.Tensor, external_feature_dict: dict) -> torch.Tensor:

@@ -54,20 +54,31 @@ class MultimodalProjector(torch.nn.Module):
 class MegatronVisionModel(torch.nn.Module):
     def __init__(self, hidden_size: int = 5120, vit_config: InternViTConfig | None = None, vision_downsample_ratio: float = 0.5,
                  vision_projector_pre_norm: bool = True, vision_model_freeze: bool = True, vision_projector_freeze: bool = False,
-                 vision_context_parallel: bool = False):
+                 vision_context_parallel: bool = False, vision_downsample_stride: int = 1):
         super().__init__()
         vit_config = vit_config or InternViTConfig()
-        if vision_downsample_ratio != 0.5:
-            raise NotImplementedError("only vision_downsample_ratio=0.5 is built")
+        # pretrain_lcvlm.py:415-420, 466-476: either the ratio form (0.5, every shipped script) or the stride form
+        vision_downsample_stride = int(vision_downsample_stride)
+        if vision_downsample_stride != 1:
+            if vision_downsample_ratio not in (1, 1.0):
+                raise NotImplementedError("vision_downsample_ratio and vision_downsample_stride together are not built: set the ratio to 1")
+        elif vision_downsample_ratio != 0.5:
+            raise NotImplementedError("only vision_downsample_ratio=0.5 (or a vision_downsample_stride) is built")
         self.vision_context_parallel = vision_context_parallel
         self.vision_downsample_ratio = vision_downsample_ratio
+        self.vision_downsample_stride = vision_downsample_stride
         self.add_class_token = vit_config.add_class_token
         self.vision_model_freeze = vision_model_freeze
         self.vision_projector_freeze = vision_projector_freeze
         self.vit = InternViTModel(vit_config, vision_context_parallel=vision_context_parallel, freeze=vision_model_freeze)
         self.vision_seq_length = self.vit.seq_length
-        self.image_token_length = int(self.vit.num_patches * vision_downsample_ratio ** 2)
-        proj_input_size = vit_config.hidden_size * int(1 / vision_downsample_ratio) ** 2
+        if vision_downsample_stride != 1:
+            side = int(round(self.vit.num_patches ** 0.5))
+            self.image_token_length = (-(-side // vision_downsample_stride)) ** 2
+            proj_input_size = vit_config.hidden_size * vision_downsample_stride ** 2
+        else:
+            self.image_token_length = int(self.vit.num_patches * vision_downsample_ratio ** 2)
+            proj_input_size = vit_config.hidden_size * int(1 / vision_downsample_ratio) ** 2
         self.vision_projection = MultimodalProjector(proj_input_size, vit_config.hidden_size, hidden_size)
         self.pre_proj_layernorm = torch.nn.LayerNorm(proj_input_size) if vision_projector_pre_norm else torch.nn.Identity()
 
@@ -82,7 +93,11 @@ class MegatronVisionModel(torch.nn.Module):
         """pretrain_lcvlm.py:453-494: [n, 3, H, W] -> [n, image_token_length, hidden]."""
         vit_output = self.vit(images, attention_mask)           # without a graph when the tower is frozen
         # class-token drop, [n, 32, 32, c] view and pixel_shuffle(0.5), flattened: one pass over the data
-        vit_output = ops.pixel_shuffle_tokens(vit_output, skip=1 if self.add_class_token else 0)
+        skip = 1 if self.add_class_token else 0
+        if self.vision_downsample_stride != 1:      # :472-476
+            vit_output = ops.pixel_shuffle_v2_tokens(vit_output, skip=skip, scale_stride=self.vision_downsample_stride)
+        else:
+            vit_output = ops.pixel_shuffle_tokens(vit_output, skip=skip)
         if self.vision_projector_freeze:
             with torch.no_grad():
                 return self.forward_projection(vit_output)
@@ -96,6 +111,11 @@ class MegatronVisionModel(torch.nn.Module):
     def forward(self, **kw_args):
         """pretrain_lcvlm.py:509-544 without vision context parallelism."""
         return self.forward_chunk(kw_args["images"], None)
+
+    def pixel_shuffle_v2(self, x, scale_stride=2):
+        """pretrain_lcvlm.py:558-570."""
+        from .vision import pixel_shuffle_v2 as _v2
+        return _v2(x, scale_stride)
 
     def pixel_shuffle(self, x, scale_factor=0.5):
         """pretrain_lcvlm.py:546-556."""

@@ -169,6 +169,19 @@ def pixel_shuffle(x: np.ndarray, scale_factor: float = 0.5) -> np.ndarray:
     return np.ascontiguousarray(x.transpose(0, 2, 1, 3))
 
 
+def pixel_shuffle_v2(x: np.ndarray, scale_stride: int = 2) -> np.ndarray:
+    """lcvlm_modellink/pretrain_lcvlm.py:558-570.  [N,W,H,C] (W == H) -> [N, ceil(W/s)*ceil(H/s), s*s*C]: zero padding on
+    the right / bottom up to a multiple of s, then every s x s patch becomes one token, its tokens in (row, column) order."""
+    n, w, h, c = x.shape
+    assert w == h
+    pl = (scale_stride - (h % scale_stride)) % scale_stride
+    x = np.pad(x, ((0, 0), (0, pl), (0, pl), (0, 0)))
+    w, h = w + pl, h + pl
+    x = x.reshape(n, w // scale_stride, scale_stride, h // scale_stride, scale_stride, c)
+    x = x.transpose(0, 1, 3, 2, 4, 5)
+    return np.ascontiguousarray(x).reshape(n, -1, scale_stride * scale_stride * c)
+
+
 def vit_tokens_to_llm_tokens(vit_output: np.ndarray, scale_factor: float = 0.5) -> np.ndarray:
     """pretrain_lcvlm.py:463-470: drop the class token, reshape to a square
     grid, pixel-shuffle, flatten to [N, 256, 4096]."""

@@ -391,6 +391,24 @@ def gen_indexing():
     print("indexing.npz:", len(out), "arrays")
 
 
+def gen_pixel_shuffle_v2():
+    """MegatronVisionModel.pixel_shuffle_v2 (lcvlm_modellink/pretrain_lcvlm.py:558-570), taken from the class body without
+    building the model: even and odd grids (the odd ones are zero-padded), strides 2 / 3 / 4, and the full-size grid as an
+    index map (value = flat source element + 1, so that the padding's zeros stay distinguishable)."""
+    pl = importlib.import_module("lcvlm_modellink.pretrain_lcvlm")
+    ps2 = pl.MegatronVisionModel.pixel_shuffle_v2
+    out = {}
+    for tag, shape, st in [("even", (2, 8, 8, 16), 2), ("odd", (2, 5, 5, 8), 2), ("s4", (1, 8, 8, 8), 4), ("s3", (1, 7, 7, 8), 3)]:
+        x = torch.arange(1, 1 + int(np.prod(shape)), dtype=torch.float32).view(*shape)
+        out[f"{tag}.in"] = x.numpy()
+        out[f"{tag}.stride"] = np.asarray(st)
+        out[f"{tag}.out"] = ps2(None, x, scale_stride=st).numpy()
+    xi = torch.arange(1, 1 + 32 * 32 * 1024, dtype=torch.int64).view(1, 32, 32, 1024)
+    out["full.index_map"] = ps2(None, xi, scale_stride=2).numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "pixel_shuffle_v2.npz"), **out)
+    print("pixel_shuffle_v2.npz:", len(out), "arrays")
+
+
 def gen_packing():
     """Qwen2Dataset.add_ret / process_ret (cognitron_vl/data/dataset_qwen2.py:132-254) run
     unbound on a namespace standing in for the dataset object.  The module is loaded by
@@ -636,7 +654,7 @@ def gen_vit():
 
 if __name__ == "__main__":
     install_shim()
-    which = sys.argv[1:] or ["eager", "eager_grad", "embedding", "indexing", "packing", "rope", "vit"]
+    which = sys.argv[1:] or ["eager", "eager_grad", "embedding", "indexing", "pixel_shuffle_v2", "packing", "rope", "vit"]
     if "eager" in which:
         gen_eager_attention()
     if "eager_grad" in which:
@@ -645,6 +663,8 @@ if __name__ == "__main__":
         gen_embedding_scatter()
     if "indexing" in which:
         gen_indexing()
+    if "pixel_shuffle_v2" in which:
+        gen_pixel_shuffle_v2()
     if "packing" in which:
         gen_packing()
     if "rope" in which:

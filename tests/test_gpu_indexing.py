@@ -36,6 +36,43 @@ def test_pixel_shuffle_matches_reference_fixture(golden_dir):
     np.testing.assert_array_equal(rec, g["ps.full.index_map"].astype(np.int64))
 
 
+def _planes(values: np.ndarray):
+    """Integer values < 2^24 as three bf16-exact planes (value % 256, value // 256 % 256, value // 65536)."""
+    v = values.astype(np.int64)
+    return [torch.from_numpy(p.astype(np.float32)).to(torch.bfloat16).cuda() for p in (v % 256, v // 256 % 256, v // 65536)]
+
+
+def test_pixel_shuffle_v2_matches_reference_fixture(golden_dir):
+    """The stride form of the token compression (pretrain_lcvlm.py:472-476, 558-570) on the HIP kernel, bit for bit
+    against outputs of the reference's own method: even and odd (zero-padded) grids, strides 2 / 3 / 4, and the full
+    32 x 32 x 1024 grid as an index map; then the fused class-token drop and the gradient (the inverse movement)."""
+    from long_vita_amd import ops, vision
+    g = np.load(os.path.join(golden_dir, "pixel_shuffle_v2.npz"))
+    for tag in ("even", "odd", "s4", "s3"):
+        st = int(g[f"{tag}.stride"])
+        lo, hi, top = (vision.pixel_shuffle_v2(p, st).float() for p in _planes(g[f"{tag}.in"]))
+        np.testing.assert_array_equal((lo + 256 * hi + 65536 * top).cpu().numpy(), g[f"{tag}.out"], err_msg=tag)
+    idx = np.arange(1, 1 + 32 * 32 * 1024, dtype=np.int64).reshape(1, 32, 32, 1024)
+    lo, hi, top = (vision.pixel_shuffle_v2(p, 2).float() for p in _planes(idx))
+    np.testing.assert_array_equal((lo + 256 * hi + 65536 * top).cpu().numpy().astype(np.int64), g["full.index_map"].astype(np.int64))
+    # class-token drop fused in, odd grid, against the oracle on the bit patterns
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 1 + 7 * 7, 64, generator=gen).to(torch.bfloat16)
+    ref = I.pixel_shuffle_v2(x[:, 1:].reshape(3, 7, 7, 64).view(torch.int16).numpy(), 2)
+    got = vision.vit_output_to_llm_tokens(x.cuda(), add_class_token=True, scale_stride=2)
+    assert got.shape == (3, 16, 256)
+    np.testing.assert_array_equal(bf16_bits(got), ref)
+    # gradient: every token's gradient comes back from the one place it went to, the class token and the padding get none
+    xg = x.cuda().requires_grad_(True)
+    w = torch.randn(3, 16, 256, generator=gen).to(torch.bfloat16).cuda()
+    (ops.pixel_shuffle_v2_tokens(xg, 1, 2).float() * w.float()).sum().backward()
+    xr = x.float().requires_grad_(True)
+    grid = torch.nn.functional.pad(xr[:, 1:].reshape(3, 7, 7, 64), (0, 0, 0, 1, 0, 1))
+    yr = grid.reshape(3, 4, 2, 4, 2, 64).permute(0, 1, 3, 2, 4, 5).flatten(3).reshape(3, -1, 256)
+    (yr * w.float().cpu()).sum().backward()
+    assert torch.equal(xg.grad.float().cpu(), xr.grad)
+
+
 def test_vit_output_to_llm_tokens_bit_exact():
     from long_vita_amd import vision
     g = torch.Generator().manual_seed(0)

@@ -217,6 +217,28 @@ def test_vision_model_chunks_of_256_images():
     assert torch.equal(whole[:256], m.forward_once(img[:256])) and torch.equal(whole[256:], m.forward_once(img[256:]))
 
 
+def test_vision_model_with_downsample_stride():
+    """--vision-downsample-stride 2 instead of the ratio form (pretrain_lcvlm.py:418-420, 472-476): an odd 5 x 5 patch grid
+    (70-pixel images) is zero-padded to 6 x 6, nine tokens of 4 x hidden channels go to the projector; the model's output
+    equals tower -> oracle's pixel_shuffle_v2 on the bit patterns -> projector."""
+    from long_vita_amd import intern_vit as iv, vision_model as vmod
+    from oracle import indexing_ref as I
+    cfg = iv.InternViTConfig(hidden_size=128, ffn_hidden_size=256, num_attention_heads=2, num_layers=1, img_h=70, img_w=70)
+    torch.manual_seed(4)
+    m = vmod.MegatronVisionModel(hidden_size=64, vit_config=cfg, vision_projector_freeze=True, vision_downsample_ratio=1,
+                                 vision_downsample_stride=2).to(torch.bfloat16).cuda()
+    assert m.image_token_length == 9 and m.vision_projection.encoder.linear_fc1.weight.shape[1] == 4 * 128
+    img = _bf(3, 3, 70, 70, seed=52).cuda()
+    out = m(images=img)
+    assert out.shape == (3, 9, 64)
+    tower = m.vit(img, None)                                  # [3, 26, 128]
+    grid = tower[:, 1:].reshape(3, 5, 5, 128).contiguous().view(torch.int16).cpu().numpy()
+    tokens = torch.from_numpy(I.pixel_shuffle_v2(grid, 2)).view(torch.bfloat16).cuda()
+    assert torch.equal(out, m.forward_projection(tokens))
+    with pytest.raises(NotImplementedError):
+        vmod.MegatronVisionModel(hidden_size=64, vit_config=cfg, vision_downsample_ratio=0.5, vision_downsample_stride=2)
+
+
 def test_image_to_llm_embedding_end_to_end():
     """One 448-pixel image through the vision model at InternViT-300M width (2 layers to keep the oracle quick):
     patch projection -> 1025 tokens -> tower -> class-token drop + pixel shuffle -> 256 tokens -> projector -> 5120 wide,

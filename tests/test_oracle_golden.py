@@ -113,6 +113,16 @@ def test_indexing_oracle_matches_reference(golden_dir):
             np.testing.assert_array_equal(I.zigzag_slice(g["rope.in"], cp, r, 0), g[f"rope.cp{cp}.r{r}"])
 
 
+def test_pixel_shuffle_v2_oracle_matches_reference_fixture(golden_dir):
+    """The stride form of the token compression (pretrain_lcvlm.py:558-570): even and odd (zero-padded) grids, strides
+    2 / 3 / 4, and the full 32 x 32 x 1024 grid as an index map, against outputs of the reference's own method."""
+    g = np.load(os.path.join(golden_dir, "pixel_shuffle_v2.npz"))
+    for tag in ("even", "odd", "s4", "s3"):
+        np.testing.assert_array_equal(I.pixel_shuffle_v2(g[f"{tag}.in"], int(g[f"{tag}.stride"])), g[f"{tag}.out"])
+    full = np.arange(1, 1 + 32 * 32 * 1024, dtype=np.int32).reshape(1, 32, 32, 1024)
+    np.testing.assert_array_equal(I.pixel_shuffle_v2(full, 2), g["full.index_map"])
+
+
 def test_pack_samples_semantics():
     pos0, n0 = I.image_token_layout(3, 2, 4)
     assert n0 == 3 + 2 * 6 and pos0.tolist() == [[4, 5, 6, 7], [10, 11, 12, 13]]
