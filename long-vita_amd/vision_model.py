@@ -33,16 +33,33 @@ class _ProjectorMLP(torch.nn.Module):
         return F.linear(inter, self.linear_fc2.weight), None
 
 
+class _ProjectorAffine(torch.nn.Module):
+    """The one linear layer of the "affine" projector (multimodal_projector.py:37-49; no bias: add_bias_linear is False,
+    pretrain_lcvlm.py:391-400).  Returns (output, bias) as Megatron's linear layers do."""
+
+    def __init__(self, input_size: int, hidden_size: int):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.empty(hidden_size, input_size))
+        torch.nn.init.normal_(self.weight, std=0.02)
+
+    def forward(self, hidden_states):
+        return F.linear(hidden_states, self.weight), None
+
+
 class MultimodalProjector(torch.nn.Module):
-    """multimodal_projector.py:9-80 with ``projector_type == "mlp"``: fc2(gelu(fc1(x))), no biases
-    (pretrain_lcvlm.py:391-400: gated_linear_unit False, add_bias_linear False, ffn = the ViT's hidden size)."""
+    """multimodal_projector.py:9-80: ``projector_type == "mlp"`` (every shipped script) is fc2(gelu(fc1(x))), no biases
+    (pretrain_lcvlm.py:391-400: gated_linear_unit False, add_bias_linear False, ffn = the ViT's hidden size); "affine"
+    (the argument's default, :962) is one linear layer ``encoder.weight``; anything else raises as the reference does."""
 
     def __init__(self, input_size: int, ffn_hidden_size: int, hidden_size: int, projector_type: str = "mlp"):
         super().__init__()
-        if projector_type != "mlp":
-            raise NotImplementedError(f"projector type {projector_type!r}: only 'mlp' is built (the shipped scripts' choice)")
         self.projector_type = projector_type
-        self.encoder = _ProjectorMLP(input_size, ffn_hidden_size, hidden_size)
+        if projector_type == "mlp":
+            self.encoder = _ProjectorMLP(input_size, ffn_hidden_size, hidden_size)
+        elif projector_type == "affine":
+            self.encoder = _ProjectorAffine(input_size, hidden_size)
+        else:
+            raise Exception(f"Unsupported multimodal projection type {projector_type}")
 
     def forward(self, hidden_states):
         encoder_output, encoder_output_bias = self.encoder(hidden_states)
@@ -54,7 +71,7 @@ class MultimodalProjector(torch.nn.Module):
 class MegatronVisionModel(torch.nn.Module):
     def __init__(self, hidden_size: int = 5120, vit_config: InternViTConfig | None = None, vision_downsample_ratio: float = 0.5,
                  vision_projector_pre_norm: bool = True, vision_model_freeze: bool = True, vision_projector_freeze: bool = False,
-                 vision_context_parallel: bool = False, vision_downsample_stride: int = 1):
+                 vision_context_parallel: bool = False, vision_downsample_stride: int = 1, vision_projector_type: str = "mlp"):
         super().__init__()
         vit_config = vit_config or InternViTConfig()
         # pretrain_lcvlm.py:415-420, 466-476: either the ratio form (0.5, every shipped script) or the stride form
@@ -79,7 +96,7 @@ class MegatronVisionModel(torch.nn.Module):
         else:
             self.image_token_length = int(self.vit.num_patches * vision_downsample_ratio ** 2)
             proj_input_size = vit_config.hidden_size * int(1 / vision_downsample_ratio) ** 2
-        self.vision_projection = MultimodalProjector(proj_input_size, vit_config.hidden_size, hidden_size)
+        self.vision_projection = MultimodalProjector(proj_input_size, vit_config.hidden_size, hidden_size, vision_projector_type)
         self.pre_proj_layernorm = torch.nn.LayerNorm(proj_input_size) if vision_projector_pre_norm else torch.nn.Identity()
 
     def forward_projection(self, vit_output):

@@ -237,6 +237,19 @@ def test_vision_model_with_downsample_stride():
     assert torch.equal(out, m.forward_projection(tokens))
     with pytest.raises(NotImplementedError):
         vmod.MegatronVisionModel(hidden_size=64, vit_config=cfg, vision_downsample_ratio=0.5, vision_downsample_stride=2)
+    # the "affine" projector (multimodal_projector.py:37-49): one linear layer after the pre-projection LayerNorm
+    ma = vmod.MegatronVisionModel(hidden_size=64, vit_config=cfg, vision_projector_type="affine").to(torch.bfloat16).cuda()
+    assert [n for n, _ in ma.vision_projection.named_parameters()] == ["encoder.weight"]
+    x = _bf(2, 4, 4 * 128, seed=53).cuda().requires_grad_(True)
+    y = ma.forward_projection(x)
+    ln = ma.pre_proj_layernorm
+    want = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (512,), ln.weight.float(), ln.bias.float(), ln.eps).to(torch.bfloat16),
+                                      ma.vision_projection.encoder.weight)
+    _close(y, want.float().cpu())
+    y.sum().backward()
+    assert x.grad is not None and ma.vision_projection.encoder.weight.grad is not None
+    with pytest.raises(Exception, match="Unsupported multimodal projection type"):
+        vmod.MultimodalProjector(8, 8, 8, "conv")
 
 
 def test_image_to_llm_embedding_end_to_end():
