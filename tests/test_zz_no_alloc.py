@@ -36,3 +36,28 @@ def test_decode_noalloc_equals_decode_two_calls_in_a_row():
     with pytest.raises(_lib.LvAttnError, match="bytes of partial results"):
         ops.decode_attention(q, k, v, 0.1, n_split=32, library_scratch=True)
     ops.decode_attention(q, k, v, 0.1, n_split=32)              # the workspace form takes the same shape
+
+
+def test_decode_noalloc_under_graph_capture():
+    """What the entry point is for: a caller under HIP graph capture cannot allocate.  One incremental-attention call is
+    captured into a graph (after one plain call on the device, which takes the buffer's address), then replayed on new
+    query / cache CONTENTS in the same tensors: each replay equals the workspace-taking entry point on those contents."""
+    from long_vita_amd import ops
+    b, k_len, hq, hkv, d = 1, 20000, 40, 8, 128
+    scale = d ** -0.5
+    q, k, v = _case(b, k_len, hq, hkv, d, 11)
+    out = torch.empty((b, hq, d), dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty((b, hq), dtype=torch.float32, device="cuda")
+    ops.decode_attention(q, k, v, scale, return_lse=True, out=out, lse=lse, library_scratch=True)   # not captured
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.decode_attention(q, k, v, scale, return_lse=True, out=out, lse=lse, library_scratch=True)
+    for seed in (12, 13):
+        q2, k2, v2 = _case(b, k_len, hq, hkv, d, seed)
+        q.copy_(q2); k.copy_(k2); v.copy_(v2)
+        out.fill_(float("nan")); lse.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        want, want_lse = ops.decode_attention(q2, k2, v2, scale, return_lse=True)
+        assert torch.equal(out, want) and torch.equal(lse, want_lse), seed
