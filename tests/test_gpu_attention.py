@@ -175,7 +175,18 @@ def test_backward_matches_oracle(name, cu, Hq, Hkv, D, causal):
         assert elementwise_excess(got, ref) <= 1.0, (name, elementwise_excess(got, ref))
 
 
-def test_forward_rising_and_falling_scores():
+@pytest.fixture(params=["default", "a4", "pp16", "lockstep"])
+def forced_forward_kernel(request):
+    """The hard-numerics tests below run under the library's own kernel choice (the ping-pong kernel at these sizes) and
+    under each other forward kernel forced by name: the one-wave kernel serves the long launches, where a float64 check of
+    every row is out of reach, so its optimistic and exact softmax passes meet the awkward inputs here."""
+    from long_vita_amd import _lib
+    _lib.check(_lib.lib().lvattn_select_fwd_kernel(request.param.encode()), "select")
+    yield request.param
+    _lib.check(_lib.lib().lvattn_select_fwd_kernel(b"default"), "select")
+
+
+def test_forward_rising_and_falling_scores(forced_forward_kernel):
     """Scores that climb steadily along the keys (the running maximum has to be raised again and
     again: the optimistic softmax pass keeps falling back to the exact one) and scores that fall
     steadily (everything after the first tiles is far below the running maximum), d = 128 and 64."""
@@ -198,7 +209,7 @@ def test_forward_rising_and_falling_scores():
                 assert err <= 2e-3 * max(1.0, np.abs(ref_lse).max() / 10), (D, sign, causal, err)
 
 
-def test_forward_rescale_branch_is_exercised():
+def test_forward_rescale_branch_is_exercised(forced_forward_kernel):
     """The kernel defers the running-max update until a row's maximum grows by more than
     2^8; spike two keys so that the update fires in the middle of the key sweep (and a
     second time later), far from the first tile, and check every row against float64."""
@@ -222,6 +233,64 @@ def test_forward_rescale_branch_is_exercised():
     ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, False)
     out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, False)
     assert rel_err(out, ref_o) <= REL_TOL
+
+
+def test_forward_extreme_score_ranges(forced_forward_kernel):
+    """Scores in the thousands (every tile's first look overflows the optimistic pass's bound, softmax rows are
+    one-hot), all-zero queries (uniform attention over the visible keys: the output is the running mean of V), and one
+    segment where both occur, d = 128 and 64, causal and full: outputs and log-sum-exp against float64."""
+    from long_vita_amd import ops
+    for D, T in ((128, 1500), (64, 700)):
+        g = torch.Generator().manual_seed(9 + D)
+        q = torch.randn(T, 4, D, generator=g) * 12.0
+        k = torch.randn(T, 2, D, generator=g) * 12.0
+        v = torch.randn(T, 2, D, generator=g)
+        q[T // 3: T // 3 + 100] = 0.0                    # uniform rows
+        q[5] = 0.0
+        q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+        scale = A.default_scale(D)
+        for causal in (True, False):
+            ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, causal)
+            out, lse = ops.attn_fwd_launch(q.cuda(), k.cuda(), v.cuda(), ops.blocks_on_device([0, T], causal, False, "cuda"), scale, causal)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all(), (D, causal)
+            assert rel_err(out, ref_o) <= REL_TOL, (D, causal, rel_err(out, ref_o))
+            err = np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse)
+            assert (err <= 1e-3 + 1e-6 * np.abs(ref_lse)).all(), (D, causal, err.max())   # fp32 log-sum-exp of scores in the thousands
+
+
+@pytest.mark.parametrize("dq_kernel,dkdv_kernel", [("default", "default"), ("lockstep", "single"), ("pp", "rs1")])
+def test_backward_hard_score_ranges(dq_kernel, dkdv_kernel):
+    """The backward kernels recompute P from the saved log-sum-exp: scores that climb along the keys with a spike (rows
+    dominated by one late key), moderately large scores (sharp but not one-hot rows) and all-zero queries (uniform rows),
+    two packed segments, d = 128 and 64: dq / dk / dv against the float64 oracle under every backward kernel pair."""
+    from long_vita_amd import ops, _lib
+    _lib.check(_lib.lib().lvattn_select_bwd_kernels(dq_kernel.encode(), dkdv_kernel.encode()), "select")
+    try:
+        for D, cu in ((128, [0, 700, 1500]), (64, [0, 300, 700])):
+            T = cu[-1]
+            g = torch.Generator().manual_seed(21 + D)
+            u = torch.randn(D, generator=g)
+            u = u / u.norm() * (D ** 0.5)
+            ramp = torch.linspace(0.0, 4.0, T)[:, None, None]
+            q = torch.randn(T, 4, D, generator=g) * 2.0 + 1.0 * u
+            k = torch.randn(T, 2, D, generator=g) * 2.0 + ramp * u
+            v = torch.randn(T, 2, D, generator=g)
+            do = torch.randn(T, 4, D, generator=g)
+            k[T // 2] = 5.0 * u
+            q[T // 3: T // 3 + 64] = 0.0
+            q, k, v, do = (t.to(torch.bfloat16) for t in (q, k, v, do))
+            scale = A.default_scale(D)
+            rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale, True)
+            qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+            out, _ = ops.varlen_attention(qc, kc, vc, cu, scale, True)
+            out.backward(do.cuda())
+            torch.cuda.synchronize()
+            for name, got, ref in (("dq", qc.grad, rdq), ("dk", kc.grad, rdk), ("dv", vc.grad, rdv)):
+                assert torch.isfinite(got.float()).all(), (D, name)
+                assert rel_err(got, ref) <= REL_TOL, (D, name, rel_err(got, ref))
+    finally:
+        _lib.check(_lib.lib().lvattn_select_bwd_kernels(b"default", b"default"), "select")
 
 
 def test_full_size_1m_prefill_rows_against_oracle_and_decode_kernel():
