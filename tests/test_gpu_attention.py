@@ -423,10 +423,11 @@ def test_dense_entry_point_strided_views_and_errors():
         ops.attn_fwd_dense_launch(q[:, :, :32], k[:, :, :32], v[:, :, :32], 0.125, False)     # head dim 32
 
 
-def test_head_dim_128_row_strides_with_and_without_256_byte_granularity():
+def test_head_dim_128_row_strides_with_and_without_256_byte_granularity(forced_forward_kernel):
     """Head dim 128: q / k / v as views of one packed [rows, (Hq + 2 Hkv) * 128] buffer (row strides that are multiples of
-    128 elements: the default kernel), and as views of a buffer with 8 padding elements per row (strides the default
-    kernel does not take: the launch falls back to the ping-pong kernel).  Both match the oracle."""
+    128 elements: every kernel takes them, the one-wave kernel included), and as views of a buffer with 8 padding elements
+    per row (strides the one-wave kernel does not take: forced or not, the launch falls back to the ping-pong kernel).
+    Both match the oracle under every forward kernel."""
     from long_vita_amd import ops
     Hq, Hkv, D = 4, 2, 128
     cu = [0, 300, 301, 1000]
