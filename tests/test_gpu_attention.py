@@ -385,7 +385,7 @@ def test_default_forward_kernel_follows_the_key_sweep():
     (37, 37, 4, 4, 64, False), (300, 300, 4, 2, 64, True),
     (700, 700, 10, 2, 128, True), (130, 450, 10, 2, 128, True),   # the second: causal rule aligned to the end of a longer key range
     (257, 513, 4, 2, 64, True), (513, 300, 5, 5, 128, False)])
-def test_dense_entry_point(rows, k_rows, Hq, Hkv, D, causal):
+def test_dense_entry_point(rows, k_rows, Hq, Hkv, D, causal, forced_forward_kernel):
     """lvattn_fwd_dense (one segment, no descriptors, workgroup size chosen from the row count) against the oracle and,
     bit for bit, against lvattn_fwd on the descriptors of the same rectangle."""
     from long_vita_amd import ops
