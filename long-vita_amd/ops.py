@@ -30,9 +30,19 @@ def _ptr(t: torch.Tensor | None) -> int:
 
 
 def _require_gpu(*tensors):
+    """Every tensor on the GPU, and on the CURRENT device: the library launches on the current device's current stream
+    with raw pointers, so a tensor of another GPU would be addressed from the wrong one."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise LvAttnError("liblvattn kernels need tensors on the GPU (there is no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise LvAttnError(f"tensor on cuda:{t.device.index} while the current device is cuda:{cur}: the library launches on "
+                              "the current device (torch.cuda.set_device / torch.cuda.device first)")
 
 
 def _last_contig(t: torch.Tensor) -> torch.Tensor:

@@ -328,3 +328,18 @@ def test_band_mode_longer_than_pre_tockens_raises():
                          actual_seq_qlen=[256, 512], actual_seq_kvlen=[256, 512])
     npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=2,
                          actual_seq_qlen=[512], actual_seq_kvlen=[512])
+
+
+
+def test_tensor_of_another_device_is_refused(monkeypatch):
+    """The launches go to the current device's current stream: a tensor that lives on another GPU must raise instead of
+    being addressed from the wrong device (one-GPU box: the current device index is faked)."""
+    from long_vita_amd import ops, _lib
+    q = torch.zeros(64, 2, 128, dtype=torch.bfloat16, device="cuda")
+    desc = ops.blocks_on_device([0, 64], True, False, "cuda")
+    real = torch.cuda.current_device()
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: real + 1)
+    with pytest.raises(_lib.LvAttnError, match="current device"):
+        ops.attn_fwd_launch(q, q, q, desc, 0.1, True)
+    with pytest.raises(_lib.LvAttnError, match="current device"):
+        ops.pixel_shuffle_tokens_launch(torch.zeros(1, 5, 8, dtype=torch.bfloat16, device="cuda"))
