@@ -160,6 +160,6 @@ def npu_prompt_flash_attention(query, key, value, num_heads=1, input_layout="BSH
     outs = []
     for i in range(b):      # one rectangle per sequence; the views keep the caller's strides
         q3, k3, v3 = query[i].unflatten(1, (num_heads, d)), key[i].unflatten(1, (hkv, d)), value[i].unflatten(1, (hkv, d))
-        desc = ops.rect_blocks_on_device(0, sq, 0, sk, causal, sk - sq, False, query.device)
-        outs.append(ops.attn_fwd_launch(q3, k3, v3, desc, scale_value, causal)[0].reshape(sq, hd))
+        # a short new block against a long cache is cut along the keys so that it fills the chip (ops.attn_fwd_rect_split_keys)
+        outs.append(ops.attn_fwd_rect_split_keys(q3, k3, v3, scale_value, causal, sk - sq)[0].reshape(sq, hd))
     return torch.stack(outs)

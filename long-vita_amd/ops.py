@@ -289,6 +289,58 @@ def merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0: int, rows: int, init:
                                   out_blk.stride(0), out_blk.stride(1), lse_acc.stride(0), _stream()), "lvattn_merge")
 
 
+def _key_pieces_for(sq: int, sk: int, hq: int, device) -> int:
+    """How many pieces to cut the key range of a (few rows) x (long cache) rectangle into: a forward work item is 256
+    query rows of one head sweeping ALL its keys, so a short query block against a long cache is a handful of very long
+    work items on a chip of hundreds of CUs.  With P pieces the launch has items * P work items of 1/P the length and
+    takes ceil(items * P / CUs) / P of the single sweep's time: the smallest P (pieces of at least 16,384 keys, at most
+    64) that gets within 3 % of the best such figure."""
+    items = -(-sq // 256) * hq
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    p_max = min(64, sk // 16384)
+    if items >= n_cu or p_max < 2:
+        return 1
+    cost = [(-(-items * p // n_cu)) / p for p in range(1, p_max + 1)]
+    best = min(cost)
+    return next(p for p, c in enumerate(cost, start=1) if c <= best * 1.03)
+
+
+def attn_fwd_rect_split_keys(q, k, v, scale: float, causal: bool, shift: int = 0, n_pieces: int | None = None):
+    """One rectangle: every row of q [Rq,Hq,D] against every row of k / v [Rk,Hkv,D]; with ``causal`` key j is visible to
+    row i iff j <= i + shift (the prompt pass over a KV cache: shift = Rk - Rq, dot_product_attention.py:440-451).
+    Returns (out [Rq,Hq,D] bf16, lse [Hq,Rq] fp32) like ``attn_fwd_launch``.
+
+    When the rectangle is a few query rows against a long key range (a follow-up turn of a few hundred tokens on a
+    1M-token cache), its key range is cut into ``n_pieces`` (chosen from the shape when None): ONE launch computes every
+    (query block, piece) pair as a work item of its own -- the query rows are replicated once per piece so that each
+    pair has its own output rows -- and the pieces' (out, lse) are merged in log-sum-exp form by the ring's merge
+    kernel.  Same result as the single sweep up to the bf16 rounding of the per-piece outputs."""
+    q, k, v = _last_contig(q), _last_contig(k), _last_contig(v)
+    _check_qkv(q, k, v)
+    sq, hq, d = q.shape
+    sk = k.shape[0]
+    dev = q.device
+    P = _key_pieces_for(sq, sk, hq, dev) if n_pieces is None else max(1, int(n_pieces))
+    vis_end = min(sk, sq + shift) if causal else sk       # keys past this are visible to no row
+    if P > 1 and vis_end > 0:
+        L = -(-(-(-vis_end // P)) // 64) * 64
+        starts = list(range(0, vis_end, L))
+        P = len(starts)
+    if P <= 1 or vis_end <= 0:
+        desc = rect_blocks_on_device(0, sq, 0, sk, causal, shift, False, dev)
+        return attn_fwd_launch(q, k, v, desc, scale, causal)
+    dense = 1 << 29                                           # a shift no row / key pair can exceed: the piece is unmasked
+    rects = [(p * sq, sq, k0, min(L, vis_end - k0), (shift - k0) if causal else dense) for p, k0 in enumerate(starts)]
+    desc = rects_blocks_on_device(rects, False, dev)
+    q_rep = q.unsqueeze(0).expand(P, sq, hq, d).reshape(P * sq, hq, d)
+    out_rep, lse_rep = attn_fwd_launch(q_rep, k, v, desc, scale, True)
+    out_acc = torch.empty((sq, hq, d), dtype=torch.float32, device=dev)
+    lse_acc = torch.empty((hq, P * sq), dtype=torch.float32, device=dev)[:, :sq]     # the pieces' row stride
+    for p in range(P):
+        merge_launch(out_acc, lse_acc, out_rep[p * sq:(p + 1) * sq], lse_rep[:, p * sq:(p + 1) * sq], 0, sq, init=(p == 0))
+    return cast_f32_to_bf16(out_acc), lse_acc.contiguous()
+
+
 # ---------------------------------------------------------------------------
 # autograd: packed variable-length attention
 # ---------------------------------------------------------------------------

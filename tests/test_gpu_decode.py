@@ -136,3 +136,58 @@ def test_sharded_cache_partials_merge_to_the_whole():
         lses.append(l)
     merged = merge_partial_attention(torch.stack(outs), torch.stack(lses))
     _check(merged, None, q, k, v, scale)
+
+
+@pytest.mark.parametrize("sq,sk,causal,pieces", [(300, 70000, True, None), (300, 70000, False, 5), (70, 40000, True, 3),
+                                                 (513, 33000, True, 7), (256, 1000, True, 4), (300, 300, True, 3)])
+def test_prompt_block_on_long_cache_split_along_the_keys(sq, sk, causal, pieces):
+    """A short block of new tokens against a long cache (dot_product_attention.py:440-451) runs as (query block, key
+    piece) work items of one launch, merged in log-sum-exp form: against the float64 oracle on the whole rectangle, and
+    against the single-sweep launch of the same rectangle (which differs only by the bf16 rounding of the pieces)."""
+    from long_vita_amd import ops
+    Hq, Hkv, D = 10, 2, 128
+    g = torch.Generator().manual_seed(sq + sk)
+    q = (torch.randn(sq, Hq, D, generator=g) * 0.8).to(torch.bfloat16)
+    k = (torch.randn(sk, Hkv, D, generator=g) * 0.8).to(torch.bfloat16)
+    v = torch.randn(sk, Hkv, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    shift = sk - sq
+    if pieces is None:
+        assert ops._key_pieces_for(sq, sk, Hq, torch.device("cuda", 0)) == 4        # 20 work items on 256 CUs, 70,000 keys: 4 pieces of >= 16,384
+    out, lse = ops.attn_fwd_rect_split_keys(q.cuda(), k.cuda(), v.cuda(), scale, causal, shift, n_pieces=pieces)
+    one, one_lse = ops.attn_fwd_rect_split_keys(q.cuda(), k.cuda(), v.cuda(), scale, causal, shift, n_pieces=1)
+    torch.cuda.synchronize()
+    assert out.shape == (sq, Hq, D) and lse.shape == (Hq, sq)
+    assert (out.float() - one.float()).abs().max().item() <= 2e-2 * one.float().abs().max().item()
+    assert (lse - one_lse).abs().max().item() <= 1e-3
+    # float64 on the rectangle: the rows are the LAST sq rows of a causal segment of sk tokens (or see every key)
+    rep = Hq // Hkv
+    qd, kd, vd = q.double(), k.double().repeat_interleave(rep, 1), v.double().repeat_interleave(rep, 1)
+    sc = torch.einsum("ihd,jhd->hij", qd, kd) * scale
+    if causal:
+        vis = torch.arange(sk)[None, :] <= (torch.arange(sq)[:, None] + shift)
+        sc = sc.masked_fill(~vis[None], float("-inf"))
+    ref_lse = torch.logsumexp(sc, dim=-1)
+    ref = torch.einsum("hij,jhd->ihd", torch.softmax(sc, dim=-1), vd)
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert (lse.double().cpu() - ref_lse).abs().max().item() <= 1e-3
+
+
+def test_prompt_flash_attention_op_takes_the_split_path():
+    """npu_prompt_flash_attention on a 200-token block against a 50,000-token cache (batch 2): equal to the one-sweep
+    rectangle to bf16 rounding, through the reference-shaped op."""
+    from long_vita_amd import ops
+    from long_vita_amd.fusion_attention import npu_prompt_flash_attention
+    b, sq, sk, Hq, Hkv, D = 2, 200, 50000, 8, 2, 128
+    g = torch.Generator(device="cuda").manual_seed(8)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.7).to(torch.bfloat16)
+    q, k, v = rnd(b, sq, Hq * D), rnd(b, sk, Hkv * D), rnd(b, sk, Hkv * D)
+    scale = D ** -0.5
+    out = npu_prompt_flash_attention(q, k, v, num_heads=Hq, input_layout="BSH", atten_mask=True, scale_value=scale,
+                                     sparse_mode=2, num_key_value_heads=Hkv)
+    assert out.shape == (b, sq, Hq * D)
+    for i in range(b):
+        desc = ops.rect_blocks_on_device(0, sq, 0, sk, True, sk - sq, False, "cuda")
+        one, _ = ops.attn_fwd_launch(q[i].unflatten(1, (Hq, D)), k[i].unflatten(1, (Hkv, D)), v[i].unflatten(1, (Hkv, D)), desc, scale, True)
+        assert (out[i].float() - one.reshape(sq, -1).float()).abs().max().item() <= 2e-2 * one.float().abs().max().item()
+
