@@ -170,6 +170,38 @@ def test_flash_attention_forward_branches_match_oracle():
         assert _rel(out3[:, bi].reshape(sv, hv, dv), ref3) <= 2e-2
 
 
+def test_flash_attention_forward_micro_batch_two_flattening_orders():
+    """Micro-batch 2 through the two packed branches, which flatten differently: the mask-reset branch goes
+    's b h d -> (b s) h d' (dot_product_attention.py:345), batch-major, matching the collate's per-row offsets of
+    actual_seq_len (data_samplers.py:46-48); the generic TND branch goes '(s b)' (:382), sequence-major.  Each output is
+    compared with the oracle run on the flattened layout the branch defines."""
+    from long_vita_amd import state
+    from long_vita_amd.core_attention import flash_attention_forward
+    g = torch.Generator().manual_seed(12)
+    s, b, hq, hkv, d = 300, 2, 4, 2, 128
+    q = torch.randn(s, b, hq, d, generator=g).to(torch.bfloat16)
+    k = torch.randn(s, b, hkv, d, generator=g).to(torch.bfloat16)
+    v = torch.randn(s, b, hkv, d, generator=g).to(torch.bfloat16)
+    # mask-reset branch: row 0 holds segments ending at 100 and 300, row 1 at 50 and 300 (+ 300 from the collate)
+    actual = [100, 300, 350, 600]
+    state.set_args(state.make_args(reset_attention_mask=True, reset_position_ids=True))
+    state.set_actual_seq_len(actual)
+    out = flash_attention_forward(_self(d), q.cuda(), k.cuda(), v.cuda(), None, None, None)
+    assert out.shape == (s, b, hq * d)
+    for row, ends in ((0, [100, 300]), (1, [50, 300])):
+        ref, _ = A.varlen_attention(q[:, row], k[:, row], v[:, row], [0] + ends, A.default_scale(d))
+        assert _rel(out[:, row].reshape(s, hq, d), ref) <= 2e-2, row
+    # generic TND branch: tokens interleave as (s b); one causal segment over the 600 flattened positions
+    state.set_args(state.make_args(shape_order="TND"))
+    state.set_actual_seq_len([s * b])
+    out2 = flash_attention_forward(_self(d), q.cuda(), k.cuda(), v.cuda(), None, None, None)
+    flat = lambda x: x.reshape(s * b, x.shape[2], d)
+    ref2, _ = A.varlen_attention(flat(q), flat(k), flat(v), [0, s * b], A.default_scale(d))
+    assert _rel(out2.reshape(s * b, hq, d), ref2) <= 2e-2
+    state.set_args(state.make_args())
+    state.set_actual_seq_len(None)
+
+
 def test_fusion_attention_layouts_agree():
     from long_vita_amd.fusion_attention import npu_fusion_attention
     g = torch.Generator().manual_seed(3)
