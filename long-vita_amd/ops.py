@@ -289,14 +289,13 @@ def merge_launch(out_acc, lse_acc, out_blk, lse_blk, row0: int, rows: int, init:
                                   out_blk.stride(0), out_blk.stride(1), lse_acc.stride(0), _stream()), "lvattn_merge")
 
 
-def _key_pieces_for(sq: int, sk: int, hq: int, device) -> int:
+def key_pieces_rule(sq: int, sk: int, hq: int, n_cu: int) -> int:
     """How many pieces to cut the key range of a (few rows) x (long cache) rectangle into: a forward work item is 256
     query rows of one head sweeping ALL its keys, so a short query block against a long cache is a handful of very long
     work items on a chip of hundreds of CUs.  With P pieces the launch has items * P work items of 1/P the length and
     takes ceil(items * P / CUs) / P of the single sweep's time: the smallest P (pieces of at least 16,384 keys, at most
     64) that gets within 3 % of the best such figure, or 1 when even the best saves less than a fifth."""
     items = -(-sq // 256) * hq
-    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
     p_max = min(64, sk // 16384, 16384 // max(1, sq))      # the query rows are replicated once per piece: at most 16,384 rows
     if items >= n_cu or p_max < 2:
         return 1
@@ -305,6 +304,10 @@ def _key_pieces_for(sq: int, sk: int, hq: int, device) -> int:
     if best > 0.8:                                         # under a fifth to gain: not worth the replicated rows and the merges
         return 1
     return next(p for p, c in enumerate(cost, start=1) if c <= best * 1.03)
+
+
+def _key_pieces_for(sq: int, sk: int, hq: int, device) -> int:
+    return key_pieces_rule(sq, sk, hq, torch.cuda.get_device_properties(device).multi_processor_count)
 
 
 def attn_fwd_rect_split_keys(q, k, v, scale: float, causal: bool, shift: int = 0, n_pieces: int | None = None):

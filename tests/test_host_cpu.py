@@ -220,3 +220,20 @@ def test_host_standins_serve_the_reference_imports(monkeypatch):
         state.set_actual_seq_len(None)
         for name in installed:
             sys.modules.pop(name, None)
+
+
+def test_key_pieces_rule_for_short_blocks_on_long_caches():
+    """The piece count of the key-split prompt pass (ops.key_pieces_rule) on a 256-CU chip with 40 query heads: enough
+    work items to fill whole rounds of the chip, pieces of at least 16,384 keys, no split when there is little to gain."""
+    from long_vita_amd.ops import key_pieces_rule
+    assert key_pieces_rule(256, 1 << 20, 40, 256) == 19       # 40 items: 19 pieces = 760 items = 3 rounds of 1/19 each
+    assert key_pieces_rule(64, 131072, 40, 256) == 6          # 240 items: one round of a sixth of the sweep
+    assert key_pieces_rule(300, 1 << 20, 40, 256) == 16       # two query blocks per head
+    assert key_pieces_rule(1024, 1 << 20, 40, 256) == 8       # 160 items -> 1280 = five full rounds
+    assert key_pieces_rule(1536, 1 << 20, 40, 256) == 1       # 240 items: nothing worth a fifth
+    assert key_pieces_rule(4096, 1 << 20, 40, 256) == 1       # already more work items than CUs
+    assert key_pieces_rule(256, 20000, 40, 256) == 1          # a short cache: no piece of 16,384 keys to cut
+    for sq, sk in ((1, 1 << 20), (200, 50000), (700, 400000)):
+        p = key_pieces_rule(sq, sk, 40, 256)
+        assert 1 <= p <= 64 and (p == 1 or sk // p >= 16384) and p * sq <= 16384
+
