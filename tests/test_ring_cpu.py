@@ -131,6 +131,43 @@ def test_segment_rects_cover_each_visible_pair_once():
         assert (cover == want.astype(int)).all(), (cp, cu)
 
 
+def test_segment_rects_exact_cover_on_random_packings():
+    """The same exact-cover property on seeded random packings: context-parallel sizes 2 / 4 / 8, chunk lengths 1 .. 12,
+    segment boundaries anywhere (on chunk edges, one-token segments, segments spanning many chunks, a single segment)."""
+    from long_vita_amd.ring_context_parallel import RingAttention
+    rng = np.random.default_rng(20240611)
+    for trial in range(60):
+        cp = int(rng.choice([2, 4, 8]))
+        c = int(rng.integers(1, 13))
+        S = 2 * cp * c
+        n_cut = int(rng.integers(0, min(S - 1, 9) + 1))
+        cuts = sorted(set(int(x) for x in rng.choice(np.arange(1, S), size=n_cut, replace=False))) if n_cut and S > 1 else []
+        if rng.random() < 0.3 and S > 2 * c:          # a boundary exactly on a chunk edge
+            cuts = sorted(set(cuts + [int(rng.integers(1, 2 * cp)) * c]))
+        cu = [0] + cuts + [S]
+        seg = np.zeros(S, dtype=int)
+        for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+            seg[a:b] = i
+        want = ((seg[:, None] == seg[None, :]) & (np.arange(S)[None, :] <= np.arange(S)[:, None])).astype(int)
+        cover = np.zeros((S, S), dtype=int)
+        for r in range(cp):
+            eng = RingAttention(None, cp, r)
+            gq = np.concatenate([np.arange(r * c, (r + 1) * c), np.arange((2 * cp - 1 - r) * c, (2 * cp - r) * c)])
+            for step in range(cp):
+                src = (r - step) % cp
+                gk = np.concatenate([np.arange(src * c, (src + 1) * c), np.arange((2 * cp - 1 - src) * c, (2 * cp - src) * c)])
+                for rects in eng.segment_rects(step, 2 * c, cu):
+                    rows = [x for q0, ql, *_ in rects for x in range(q0, q0 + ql)]
+                    keys = [x for _, _, k0, kl, _ in rects for x in range(k0, k0 + kl)]
+                    assert len(rows) == len(set(rows)) and len(keys) == len(set(keys)), (cp, c, cu)
+                    for q0, ql, k0, kl, sh in rects:
+                        assert ql > 0 and kl > 0 and 0 <= q0 and q0 + ql <= 2 * c and 0 <= k0 and k0 + kl <= 2 * c, (cp, c, cu)
+                        for i in range(ql):
+                            for j in range(min(kl, max(0, i + sh + 1))):
+                                cover[gq[q0 + i], gk[k0 + j]] += 1
+        assert (cover == want).all(), (trial, cp, c, cu)
+
+
 def _gloo_worker(rank, world, port, S, Hq, Hkv, D, scale, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
