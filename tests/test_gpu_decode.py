@@ -173,6 +173,27 @@ def test_prompt_block_on_long_cache_split_along_the_keys(sq, sk, causal, pieces)
     assert (lse.double().cpu() - ref_lse).abs().max().item() <= 1e-3
 
 
+def test_prompt_block_pieces_long_enough_for_the_one_wave_kernel():
+    """Key pieces of 70,000 keys: the library runs them on the one-wave-per-SIMD forward kernel (a work item's sweep is
+    what selects it), here with a query block of 300 rows only, the second work item of a head holding 44 of them."""
+    from long_vita_amd import ops
+    sq, sk, Hq, Hkv, D = 300, 140000, 2, 1, 128
+    g = torch.Generator().manual_seed(5)
+    q = (torch.randn(sq, Hq, D, generator=g) * 0.8).to(torch.bfloat16)
+    k = (torch.randn(sk, Hkv, D, generator=g) * 0.8).to(torch.bfloat16)
+    v = torch.randn(sk, Hkv, D, generator=g).to(torch.bfloat16)
+    scale, shift = A.default_scale(D), sk - sq
+    out, lse = ops.attn_fwd_rect_split_keys(q.cuda(), k.cuda(), v.cuda(), scale, True, shift, n_pieces=2)
+    torch.cuda.synchronize()
+    qd, kd, vd = q.double(), k.double().repeat_interleave(Hq // Hkv, 1), v.double().repeat_interleave(Hq // Hkv, 1)
+    sc = torch.einsum("ihd,jhd->hij", qd, kd) * scale
+    vis = torch.arange(sk)[None, :] <= (torch.arange(sq)[:, None] + shift)
+    sc = sc.masked_fill(~vis[None], float("-inf"))
+    ref = torch.einsum("hij,jhd->ihd", torch.softmax(sc, dim=-1), vd)
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert (lse.double().cpu() - torch.logsumexp(sc, dim=-1)).abs().max().item() <= 1e-3
+
+
 def test_prompt_flash_attention_op_takes_the_split_path():
     """npu_prompt_flash_attention on a 200-token block against a 50,000-token cache (batch 2): equal to the one-sweep
     rectangle to bf16 rounding, through the reference-shaped op."""
