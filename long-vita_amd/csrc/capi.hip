@@ -24,8 +24,9 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" int lvattn_abi_version(void) { return 1; }
 
-// Forward kernel choice.  Default: the one-wave-per-SIMD kernel ("a4") for head dim 128 (launches of at least 65,536 query
-// rows; smaller ones take "pp") and the lockstep kernel for head dim 64; the ping-pong kernel ("pp") carries the fused rotary embedding and stays selectable, as do pp16 and
+// Forward kernel choice.  Default: the one-wave-per-SIMD kernel ("a4") for head dim 128 when a work item sweeps at least
+// 32,768 keys on average (shorter sweeps take "pp", see fwd_a4 below) and the lockstep kernel for head dim 64; the ping-pong
+// kernel ("pp") carries the fused rotary embedding and stays selectable, as do pp16 and
 // lockstep (a4 +1.8 % over pp at 1M tokens, pp +13 % over lockstep at d = 128, lockstep +16 % over pp at d = 64).  The
 // environment variable LVATTN_FWD_KERNEL=a4 / pp / pp16 / lockstep forces one (a4 and pp16 exist for d = 128 only:
 // other head dims then take their default).
