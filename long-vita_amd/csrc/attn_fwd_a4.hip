@@ -1,4 +1,4 @@
-// Flash-style attention forward for gfx950, "one wave per SIMD" form (head dim 128; the default for long launches,
+// Flash-style attention forward for gfx950, "one wave per SIMD" form (head dim 128; the default when a work item sweeps at least 32,768 keys,
 // LVATTN_FWD_KERNEL=a4 forces it).
 //
 // One workgroup = 4 waves = one 256-row query block of one query head.  A wave owns 64 query rows (two 32-row column
