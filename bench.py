@@ -3,6 +3,9 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--seq S]
 
+With N > 1 either launch it under torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or run it plainly: without WORLD_SIZE it starts its own N ranks and relays rank 0's line.
+
 Default workload ``prefill_1m``: one layer's causal attention prefill over a
 1,048,576-token packed context with Qwen2.5-14B heads (40 query / 8 KV heads,
 d = 128, bf16), single causal segment (the reference's stage-3/4 semantics:
@@ -55,12 +58,50 @@ def parse():
     return ap.parse_args()
 
 
+def launch_command(n, argv, port):
+    """The command line that starts ``n`` ranks of this script on this node (one process per GPU, rendezvous on the
+    loopback address), as the reference's launch scripts do with torchrun (scripts/modellink/qwen25/
+    finetune_qwen25_14b_intern_300m_ptd_tp8pp1_stage4.sh:239: starting the ranks is the script's job, not its caller's)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` without a launcher around it: this process has made no GPU call yet and makes none;
+    it starts the N ranks as a child job, relays rank 0's JSON line and returns the job's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")       # torchrun would otherwise pin every rank to one host thread
+    proc = subprocess.Popen(launch_command(n, argv, free_port()), stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:                                      # anything else a rank prints is not part of the contract's one line
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, saw {lines}\n")
+        rc = 1
+    return rc
+
+
 def dist_setup(n):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if n > 1 and world != n:
-        raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run); got {world}")
+        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}: the launcher started a different number of ranks")
     # LV_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (RCCL refuses two
     # ranks on one device); ranks then share devices round-robin.  The judged runs use nccl (= RCCL).
     backend = os.environ.get("LV_BENCH_BACKEND", "nccl")
@@ -109,7 +150,7 @@ def causal_fwd_flops(lengths, hq=None, d=D):
     return sum(2.0 * d * hq * float(L) * float(L) for L in lengths)
 
 
-def cpu_baseline(seq, rows=1024, heads=(0, 1)):
+def cpu_baseline(seq, rows=2048, heads=(0, 1)):
     """The reference's eager attention path (oracle restatement of
     dot_product_attention.py:183-286) on ``rows`` query rows x all keys x
     ``heads`` query heads, extrapolated linearly in rows x heads: the eager path
@@ -186,6 +227,8 @@ def profiled_traffic(summary_name, kernel):
 def main():
     global HQ, HKV
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if args.heads:
         HQ, HKV = (int(x) for x in args.heads.split(","))
     rank, world, local = dist_setup(args.gpus)
