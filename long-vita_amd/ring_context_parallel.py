@@ -94,32 +94,61 @@ class HipBackend:
 
 
 class TorchDistComm:
-    """Point-to-point ring traffic through torch.distributed (RCCL on GPUs, gloo on CPU),
-    issued on a side stream so that it overlaps the block kernel."""
+    """Point-to-point ring traffic through torch.distributed (RCCL on GPUs, gloo on CPU), issued on side streams so that
+    it overlaps the block kernels.
 
-    def __init__(self, group, device):
+    ``overlap_group`` is the second communicator the reference sets up with --use-cp-send-recv-overlap
+    (``cp_group_for_send_recv_overlap``, dot_product_attention.py:59-60): with it a rank's send and its receive go
+    through DIFFERENT communicators, i.e. two RCCL kernels that progress side by side instead of one grouped call.  A
+    message from ring rank a to a + 1 travels on ``group`` when a is even and on ``overlap_group`` when a is odd, so
+    both ends of every pair agree (even ranks send on ``group`` and receive on ``overlap_group``, odd ranks the other
+    way round); that needs an even ring size, an odd ring keeps to ``group``.
+
+    ``lane`` selects the side stream: lane 0 carries the K / V blocks, lane 1 the fp32 running sums of dK / dV in the
+    backward pass, so a 1 GiB sum in flight never delays the K / V block the next step's kernels wait for."""
+
+    def __init__(self, group, device, overlap_group=None, ring_rank: int = 0, ring_size: int = 0):
         self.group = group
+        self.overlap_group = overlap_group if (overlap_group is not None and ring_size % 2 == 0) else None
+        self.ring_rank = int(ring_rank)
         self.cuda = device.type == "cuda"
-        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(2)] if self.cuda else None
 
-    def exchange(self, send_bufs, recv_bufs, dst, src):
-        """Post isend(send_bufs -> dst) and irecv(recv_bufs <- src) as one group; returns a
-        handle for wait().  The traffic starts once everything already queued on the
-        compute stream has finished (the receive buffer may still be in use there)."""
-        p2p = []
-        for s in send_bufs:
-            p2p.append(dist.P2POp(dist.isend, s, dst, self.group))
-        for r in recv_bufs:
-            p2p.append(dist.P2POp(dist.irecv, r, src, self.group))
+    @property
+    def stream(self):
+        return self.streams[0] if self.cuda else None
+
+    def _post(self, send_bufs, recv_bufs, dst, src):
+        if self.overlap_group is None:
+            p2p = [dist.P2POp(dist.isend, s, dst, self.group) for s in send_bufs]
+            p2p += [dist.P2POp(dist.irecv, r, src, self.group) for r in recv_bufs]
+            return dist.batch_isend_irecv(p2p)
+        even = self.ring_rank % 2 == 0
+        send_group, recv_group = (self.group, self.overlap_group) if even else (self.overlap_group, self.group)
+        sends = [dist.P2POp(dist.isend, s, dst, send_group) for s in send_bufs]
+        recvs = [dist.P2POp(dist.irecv, r, src, recv_group) for r in recv_bufs]
+        reqs = []
+        # each communicator sees its two ends post in the same relative order: on `group` the even rank's send meets
+        # the odd rank's receive first, on the overlap group the odd rank's send meets the even rank's receive second
+        for batch in ((sends, recvs) if even else (recvs, sends)):
+            if batch:
+                reqs += dist.batch_isend_irecv(batch)
+        return reqs
+
+    def exchange(self, send_bufs, recv_bufs, dst, src, lane: int = 0):
+        """Post isend(send_bufs -> dst) and irecv(recv_bufs <- src); returns a handle for wait().  The traffic starts
+        once everything already queued on the compute stream has finished (the receive buffer may still be in use
+        there)."""
         if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                for r in dist.batch_isend_irecv(p2p):
+            stream = self.streams[lane]
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                for r in self._post(send_bufs, recv_bufs, dst, src):
                     r.wait()          # stream-level wait on the side stream; the host does not block
                 done = torch.cuda.Event()
-                done.record(self.stream)
+                done.record(stream)
             return done
-        return dist.batch_isend_irecv(p2p)
+        return self._post(send_bufs, recv_bufs, dst, src)
 
     def wait(self, handle):
         if self.cuda:
@@ -133,28 +162,47 @@ class RingAttention:
     """Engine for one context-parallel group.  ``rank`` is the rank inside the CP group;
     ``global_ranks[i]`` the global rank of CP rank i (defaults to 0..cp-1)."""
 
-    def __init__(self, group, cp_size: int, rank: int, causal: bool = True, global_ranks=None, backend=None, comm=None):
+    def __init__(self, group, cp_size: int, rank: int, causal: bool = True, global_ranks=None, backend=None, comm=None,
+                 overlap_group=None):
         self.group = group
+        self.overlap_group = overlap_group
         self.cp = int(cp_size)
         self.rank = int(rank)
         self.causal = bool(causal)
         self.global_ranks = list(global_ranks) if global_ranks is not None else list(range(self.cp))
         self.backend = backend
         self.comm = comm
-        self._ws: dict = {}        # buffers of forward / backward, allocated once per shape
+        self._ws: dict = {}        # pass ("fwd" / "bwd") -> (shape key, buffers): one set per pass, the latest shape
         self.profile = False       # record per-step device timestamps into self.timeline (forward)
         self.timeline: list = []
 
     def _buffers(self, key, make):
-        """Per-engine workspace: every buffer of a pass is allocated the first time its shape is seen and reused by
-        every later call (a caching allocator under RCCL traffic can synchronise; a steady-state step allocates
-        nothing).  A result that leaves the engine is the caller's from then on, so those are allocated per call."""
-        hit = self._ws.get(key)
-        if hit is None:
-            if len(self._ws) >= 4:             # a shape change (new sequence length) retires the oldest set
-                self._ws.pop(next(iter(self._ws)))
-            hit = self._ws[key] = make()
-        return hit
+        """Per-engine workspace: the buffers of a pass are allocated the first time a shape is seen and reused by every
+        later call with that shape (a caching allocator under RCCL traffic can synchronise; a steady-state step
+        allocates nothing).  One set per pass is kept: a new shape (another sequence length) frees the old set before
+        the new one is made, so what stays resident is at most one forward set (fp32 running output + one bf16 block
+        output + two K / V buffers: 5.1 GB at 131,072 local tokens, 40 / 8 heads) and one backward set (fp32 dq, three
+        fp32 K/V-shaped buffers, two K / V buffers: 7.0 GB).  ``release()`` frees them.  A result that leaves the engine
+        is the caller's from then on, so those are allocated per call."""
+        hit = self._ws.get(key[0])
+        if hit is None or hit[0] != key:
+            self._ws.pop(key[0], None)        # drop the old shape's set first: both need not be resident at once
+            hit = self._ws[key[0]] = (key, make())
+        return hit[1]
+
+    def release(self):
+        """Free the workspace (e.g. between a training phase and an evaluation at another sequence length, or before
+        the engine goes idle); the next call allocates it again."""
+        self._ws.clear()
+
+    def workspace_bytes(self) -> int:
+        def size(x):
+            if isinstance(x, torch.Tensor):
+                return x.numel() * x.element_size()
+            if isinstance(x, (list, tuple)):
+                return sum(size(y) for y in x)
+            return 0
+        return sum(size(v) for _, bufs in self._ws.values() for v in bufs.values())
 
     def step_stats(self):
         """After a profiled forward and a device synchronisation: milliseconds per ring step as a list of
@@ -174,8 +222,13 @@ class RingAttention:
 
     def _comm(self, device):
         if self.comm is None:
-            self.comm = TorchDistComm(self.group, device)
+            self.comm = TorchDistComm(self.group, device, self.overlap_group, self.rank, self.cp)
         return self.comm
+
+    def _exchange(self, side, send_bufs, recv_bufs, dst, src, lane):
+        if lane and isinstance(side, TorchDistComm):
+            return side.exchange(send_bufs, recv_bufs, dst, src, lane)
+        return side.exchange(send_bufs, recv_bufs, dst, src)     # test transports have one lane
 
     def step_rect(self, step: int, s_loc: int):
         """(q_rect, k_rect, causal, shift) of ring step ``step`` on a rank holding ``s_loc`` rows."""
@@ -371,7 +424,7 @@ class RingAttention:
                 else:                       # step 0 touches every key row of the local block
                     send.copy_(dloc)
                 # after the last step this hop returns the finished sum to the block's owner
-                pending = side.exchange([send], [dbuf[step % 2]], nxt, prv)
+                pending = self._exchange(side, [send], [dbuf[step % 2]], nxt, prv, 1)    # its own side stream
         if cp > 1:
             side.wait(pending)
             final = dbuf[(cp - 1) % 2]
@@ -450,12 +503,39 @@ class _RingRopeAttnFunction(torch.autograd.Function):
 _engines: dict = {}
 
 
+def _group_ranks(group):
+    """What identifies a process group across its lifetime: the global ranks in it (an ``id()`` can be handed to a new
+    object once the old group is gone)."""
+    if group is None or not dist.is_available() or not dist.is_initialized():
+        return None
+    try:
+        return tuple(dist.get_process_group_ranks(group))
+    except Exception:       # a group from another backend wrapper: fall back to what the caller listed
+        return None
+
+
+def _engine_for(group, overlap, cp_size, rank, causal, ranks):
+    """The engine of one context-parallel group, kept across calls for its workspace and side streams.  Keyed by the
+    group's member ranks; an entry whose group objects are not the ones passed now (the group was destroyed and made
+    again) is replaced, never reused."""
+    key = (_group_ranks(group), cp_size, rank, causal, tuple(ranks) if ranks is not None else None)
+    eng = _engines.get(key)
+    if eng is not None and (eng.group is not group or eng.overlap_group is not overlap):
+        eng.release()
+        eng = None
+    if eng is None:
+        eng = RingAttention(group, cp_size, rank, causal=causal, global_ranks=ranks, overlap_group=overlap)
+        _engines[key] = eng
+    return eng
+
+
 def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask=None, dropout_p=0.,
                               actual_seq_qlen=None, actual_seq_kvlen=None, rope=None):
     """Drop-in for mindspeed.core.context_parallel.ring_context_parallel.ringattn_context_parallel
     as called at dot_product_attention.py:70-71.
 
-    ``cp_para`` keys read: causal, cp_group, cp_size, rank, cp_global_ranks (the double-ring
+    ``cp_para`` keys read: causal, cp_group, cp_size, rank, cp_global_ranks, cp_group_for_send_recv_overlap (the second
+    communicator of --use-cp-send-recv-overlap: sends and receives then use different communicators); (the double-ring
     window keys cp_inner_ranks / cp_outer_ranks / ... are accepted and must describe a single
     ring: one 8-GPU node has no inter-node window), pse must be None.
 
@@ -483,12 +563,10 @@ def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask
     cp_size = int(cp_para["cp_size"])
     rank = int(cp_para["rank"])
     group = cp_para.get("cp_group")
+    overlap = cp_para.get("cp_group_for_send_recv_overlap")
     ranks = cp_para.get("cp_global_ranks")
-    key = (id(group), cp_size, rank, bool(cp_para.get("causal", True)), tuple(ranks) if ranks is not None else None)
-    eng = _engines.get(key)
-    if eng is None:
-        eng = RingAttention(group, cp_size, rank, causal=bool(cp_para.get("causal", True)), global_ranks=ranks)
-        _engines[key] = eng
+    causal = bool(cp_para.get("causal", True))
+    eng = _engine_for(group, overlap, cp_size, rank, causal, ranks)
     d = q.shape[-1] // n
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
     if rope is not None:

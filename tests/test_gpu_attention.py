@@ -1,7 +1,7 @@
 """GPU parity tests of the attention kernels (through the C ABI) against the CPU
 oracle.  Tolerances are the ones the project states for bf16.  Outputs and gradients, tensor level:
 max|got - ref| <= 2e-2 * max|ref| (``rel_err``); per element: |got - ref| <= 2e-2 * |ref| + 5e-3 * max|ref|
-(``elementwise_excess``).  LSE within 1e-3 absolute."""
+(``elementwise_excess``).  LSE within 1e-3 absolute; the hard-numerics tests use the tighter, relative ``lse_bound``."""
 import os
 import zlib
 
@@ -15,6 +15,15 @@ from oracle import attention_ref as A
 
 REL_TOL = 2e-2
 LSE_TOL = 1e-3
+
+
+def lse_bound(ref_lse: np.ndarray) -> np.ndarray:
+    """The log-sum-exp bound of the hard-numerics tests: 6 * 2^-23 * max(1, |lse|), i.e. six units in the last place of
+    an fp32 number of that magnitude.  Measured on those tests' inputs under every forward kernel (tools_diag/lse_err.py):
+    at most 2.8 such units (1.5e-4 absolute at |lse| = 839, 3.3e-5 at 141, 8.6e-7 at 3.5).  The bound stays below the
+    1e-3 absolute of the ordinary tests up to |lse| = 1398; fp32 itself cannot hold 1e-3 once |lse| passes 8192 (one
+    unit in the last place is 9.8e-4 there), which is why the rule is relative."""
+    return 6.0 * 2.0 ** -23 * np.maximum(1.0, np.abs(ref_lse))
 
 
 def rel_err(got: torch.Tensor, ref: np.ndarray) -> float:
@@ -205,8 +214,8 @@ def test_forward_rising_and_falling_scores(forced_forward_kernel):
                 ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, causal)
                 out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, causal)
                 assert rel_err(out, ref_o) <= REL_TOL, (D, sign, causal)
-                err = np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max()
-                assert err <= 2e-3 * max(1.0, np.abs(ref_lse).max() / 10), (D, sign, causal, err)
+                err = np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse)
+                assert (err <= lse_bound(ref_lse)).all(), (D, sign, causal, err.max())
 
 
 def test_forward_rescale_branch_is_exercised(forced_forward_kernel):
@@ -228,11 +237,12 @@ def test_forward_rescale_branch_is_exercised(forced_forward_kernel):
     ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, True)
     out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, True)
     assert rel_err(out, ref_o) <= REL_TOL
-    assert np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse).max() <= 2e-3 * max(1.0, np.abs(ref_lse).max() / 10)
+    assert (np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse) <= lse_bound(ref_lse)).all()
     # non-causal: every row meets both spikes
     ref_o, ref_lse = A.varlen_attention(q, k, v, [0, T], scale, False)
     out, lse = ops.varlen_attention(q.cuda(), k.cuda(), v.cuda(), [0, T], scale, False)
     assert rel_err(out, ref_o) <= REL_TOL
+    assert (np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse) <= lse_bound(ref_lse)).all()
 
 
 def test_forward_extreme_score_ranges(forced_forward_kernel):
@@ -256,7 +266,7 @@ def test_forward_extreme_score_ranges(forced_forward_kernel):
             assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all(), (D, causal)
             assert rel_err(out, ref_o) <= REL_TOL, (D, causal, rel_err(out, ref_o))
             err = np.abs(lse.cpu().numpy().astype(np.float64) - ref_lse)
-            assert (err <= 1e-3 + 1e-6 * np.abs(ref_lse)).all(), (D, causal, err.max())   # fp32 log-sum-exp of scores in the thousands
+            assert (err <= lse_bound(ref_lse)).all(), (D, causal, err.max())   # fp32 log-sum-exp of scores in the thousands
 
 
 @pytest.mark.parametrize("dq_kernel,dkdv_kernel", [("default", "default"), ("lockstep", "single"), ("pp", "rs1")])

@@ -109,6 +109,70 @@ def test_scatter_features_bit_exact(golden_dir):
     np.testing.assert_array_equal(bf16_bits(got3), emb.view(torch.int16).numpy())
 
 
+@pytest.mark.parametrize("S,cp", [(64, 2), (256, 4), (1024, 8)])
+def test_cp_image_index_remap_on_device_matches_reference(golden_dir, S, cp):
+    """The image-index remap of the CP partition on DEVICE tensors, where the reference builds it
+    (lcvlm_modellink/training/utils.py:271-281 selects the images a rank touches, :314-333 builds the (image, slot)
+    source and (row, local position) target indices with index_of_a_in_b :539-542): selected images, src / tgt indices,
+    tokens and position ids bit-exact against the fixture made by the reference's own function, for every rank; the
+    device-built indices then drive the HIP scatter, against the oracle's scatter on the fixture's indices."""
+    from long_vita_amd import cp_partition as P, state, vision
+    g = np.load(os.path.join(golden_dir, "indexing.npz"))
+    tag = f"zz.S{S}.cp{cp}"
+    ext = torch.from_numpy(g[f"{tag}.external_indices"])
+    n_img, n_tok, h = ext.shape[1], ext.shape[2], 64
+    gen = torch.Generator().manual_seed(S + cp)
+    feats_all = torch.randn(n_img, n_tok, h, generator=gen).to(torch.bfloat16)
+    dev = torch.device("cuda", 0)
+    for r in range(cp):
+        state.set_args(state.make_args(seq_length=S, context_parallel_size=cp))
+        state.mpu.initialize(None, cp, r)
+
+        def batch(images):
+            return {"tokens": torch.from_numpy(g[f"{tag}.tokens"]).to(dev), "position_ids": torch.arange(S).repeat(2, 1).to(dev),
+                    "attention_mask": None, "external_images": images.to(dev), "external_indices": ext.clone().to(dev)}
+        out = P.get_batch_on_this_cp_rank(batch(torch.from_numpy(g[f"{tag}.images"])))
+        assert all(v.is_cuda for k, v in out.items() if v is not None)
+        np.testing.assert_array_equal(out["tokens"].cpu().numpy(), g[f"{tag}.r{r}.tokens"])
+        np.testing.assert_array_equal(out["position_ids"].cpu().numpy(), g[f"{tag}.r{r}.position_ids"])
+        np.testing.assert_array_equal(out["external_images"].cpu().numpy(), g[f"{tag}.r{r}.images"])
+        assert "external_indices" not in out
+        if f"{tag}.r{r}.src" not in g.files:
+            assert "external_src_indices" not in out
+            continue
+        src, tgt = out["external_src_indices"], out["external_tgt_indices"]
+        assert src.dtype == torch.int64 and tgt.dtype == torch.int64
+        np.testing.assert_array_equal(src.cpu().numpy(), g[f"{tag}.r{r}.src"])
+        np.testing.assert_array_equal(tgt.cpu().numpy(), g[f"{tag}.r{r}.tgt"])
+        # the same partition carrying per-image features instead of pixels: what the encoder of this rank would return
+        fsel = P.get_batch_on_this_cp_rank(batch(feats_all))["external_images"]
+        assert fsel.shape[0] == g[f"{tag}.r{r}.images"].shape[0]
+        emb = torch.randn(2, S // cp, h, generator=gen).to(torch.bfloat16)
+        ref = I.scatter_features(emb.view(torch.int16).numpy(), fsel.cpu().view(torch.int16).numpy(),
+                                 src_indices=g[f"{tag}.r{r}.src"], tgt_indices=g[f"{tag}.r{r}.tgt"])
+        got = vision.scatter_external_features(emb.clone().to(dev), {"features": fsel, "src_indices": src, "tgt_indices": tgt})
+        np.testing.assert_array_equal(bf16_bits(got), ref)
+
+
+def test_index_of_a_in_b_on_device(golden_dir):
+    from long_vita_amd.cp_partition import index_of_a_in_b
+    g = np.load(os.path.join(golden_dir, "indexing.npz"))
+    got = index_of_a_in_b(torch.from_numpy(g["ioab.a"]).cuda(), torch.from_numpy(g["ioab.b"]).cuda())
+    assert got.is_cuda
+    np.testing.assert_array_equal(got.cpu().numpy(), g["ioab.out"])
+    # a 1M-token rank's worth: positions of 4096 frames x 256 slots inside a CP = 8 rank's zig-zag index
+    S, cp, r = 1 << 20, 8, 5
+    calib = P_zigzag(S, cp, r)
+    pick = calib[torch.randperm(calib.numel(), generator=torch.Generator().manual_seed(0))[:65536]]
+    got = index_of_a_in_b(pick.cuda(), calib.cuda())
+    assert torch.equal(calib.cuda()[got], pick.cuda())
+
+
+def P_zigzag(S, cp, r):
+    from long_vita_amd import cp_partition as P
+    return P.zigzag_index(S, cp, r)
+
+
 def test_zigzag_gather_on_gpu_bit_exact():
     from long_vita_amd import cp_partition as P
     table = torch.arange(4096 * 128, dtype=torch.float32).reshape(4096, 1, 1, 128)

@@ -326,50 +326,6 @@ def test_ring_forward_with_rotary_embedding_folded_in(cp, cu, kernel_with_rotati
     assert all(run_virtual_ranks(cp, body))
 
 
-class _FeedCommBwd(_FeedComm):
-    """The feed transport for a backward pass of ONE rank: K / V blocks arrive as in the forward; the running dK / dV
-    sum that would arrive from the previous rank is replaced by zeros (fp32 buffers), so only this rank's dQ, which is
-    complete on its own, is meaningful."""
-
-    def exchange(self, send_bufs, recv_bufs, dst, src):
-        if recv_bufs[0].dtype == torch.float32:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                recv_bufs[0].zero_()
-                done = torch.cuda.Event()
-                done.record(self.stream)
-            return done
-        return super().exchange(send_bufs, recv_bufs, dst, src)
-
-
-def test_full_size_ring_backward_rank_equals_single_launch_1m():
-    """Backward of one CP = 8 rank at 1,048,576 tokens (eight ring steps: the three kinds of rectangle through the dQ
-    and dK/dV kernels with fp32 accumulation): the rank's dQ against the same rows of ONE whole-context backward, and
-    the rank's own-block dK / dV contribution of step 0 is exercised through the same launch."""
-    from long_vita_amd import ops
-    from long_vita_amd.ring_context_parallel import RingAttention
-    S, Hq, Hkv, D, cp, r = 1048576, 40, 8, 128, 8, 5
-    dev = torch.device("cuda")
-    g = torch.Generator(device=dev).manual_seed(12)
-    rnd = lambda *shape: (torch.randn(*shape, generator=g, device=dev) * 0.5).to(torch.bfloat16)
-    q, k, v, do = rnd(S, Hq, D), rnd(S, Hkv, D), rnd(S, Hkv, D), rnd(S, Hq, D)
-    scale = A.default_scale(D)
-    desc_q = ops.blocks_on_device([0, S], True, False, dev)
-    desc_k = ops.blocks_on_device([0, S], True, True, dev)
-    whole, whole_lse = ops.attn_fwd_launch(q, k, v, desc_q, scale, True)
-    dq_all, dk_all, dv_all, _ = ops.attn_bwd_launch(q, k, v, whole, do, whole_lse, desc_q, desc_k, scale, True)
-    s_loc = S // cp
-    ql, kl, vl, ol, dl = (zigzag_local(x, cp, r).reshape(s_loc, 1, -1).contiguous() for x in (q, k, v, whole, do))
-    lse_l = zigzag_local(whole_lse.t(), cp, r).t().contiguous()
-    eng = RingAttention(None, cp, r, causal=True, comm=_FeedCommBwd(r, cp, k, v))
-    dq, dk, dv = eng.backward(ql, kl, vl, ol, lse_l, dl, Hq, scale)
-    torch.cuda.synchronize()
-    want = zigzag_local(dq_all, cp, r).float()
-    err = (dq.reshape(s_loc, Hq, D).float() - want).abs().max().item()
-    assert err <= REL_TOL * want.abs().max().item(), err
-    assert torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all()
-
-
 def _rope_case(S, seed):
     from oracle import rope_ref as R
     Hq, Hkv, D = 10, 2, 128

@@ -199,3 +199,32 @@ def test_scatter_oracle_matches_reference_embedding_forward(golden_dir):
         dwe, df = I.scatter_features_grad(do.transpose(1, 0, 2), feats.shape, **kw)
         np.testing.assert_array_equal(dwe, _bits_to_f32(g[f"{tag}.dwe"]), err_msg=tag)
         np.testing.assert_array_equal(df, ref_df, err_msg=tag)
+
+
+def test_sampled_gradient_rows_equal_the_full_float64_backward():
+    """oracle/sampled_rows.py (one row of dq / dk / dv at a time, what the full-size GPU tests use) against the whole
+    float64 backward on packed segments with a 5:1 head ratio: to 1e-12."""
+    from oracle import sampled_rows as R
+    cu = [0, 37, 38, 200, 333]
+    T, Hq, Hkv, D = cu[-1], 10, 2, 32
+    g = torch.Generator().manual_seed(3)
+    q, k, v, do = (torch.randn(T, H, D, generator=g).to(torch.bfloat16) for H in (Hq, Hkv, Hkv, Hq))
+    scale = A.default_scale(D)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale, True)
+    ro, rl = A.varlen_attention(q, k, v, cu, scale, True)
+    rep = Hq // Hkv
+    for a, b in zip(cu[:-1], cu[1:]):
+        for i in {a, (a + b) // 2, b - 1}:
+            for h in (0, 7):
+                dq, l, o = R.dq_row(q, k, v, do, i, h, (a, b), scale)
+                assert np.abs(dq.numpy() - rdq[i, h]).max() < 1e-12 and abs(float(l) - rl[h, i]) < 1e-12
+                assert np.abs(o.numpy() - ro[i, h]).max() < 1e-12
+        for gkv in range(Hkv):
+            r0 = a + (b - a) // 3                                  # statistics from a row inside the segment onwards
+            lse, delta = R.row_stats(q, k, v, do, list(range(gkv * rep, gkv * rep + rep)), (a, b), (r0, b), scale, chunk=50)
+            assert np.abs(lse.numpy() - rl[gkv * rep:gkv * rep + rep, r0:b]).max() < 1e-12
+            for j in {r0, (r0 + b) // 2, b - 1}:
+                dk, dv = R.dkdv_row(q, k, v, do, j, gkv, (a, b), lse, delta, r0, scale)
+                assert np.abs(dk.numpy() - rdk[j, gkv]).max() < 1e-12 and np.abs(dv.numpy() - rdv[j, gkv]).max() < 1e-12
+    assert R.row_excess(torch.tensor([1.0, 0.0]), torch.tensor([1.0, 0.0])) == 0.0
+    assert R.row_excess(torch.tensor([1.03, 0.0]), torch.tensor([1.0, 0.0])) > 1.0
