@@ -210,7 +210,7 @@ def cpu_baseline_cfg1():
 
 def profiled_traffic(summary_name, kernel):
     """Memory-side bytes per launch of `kernel`, from the committed rocprofv3 PMC passes of this same
-    command (profiles/<summary_name>; collected with tools_prof.sh in separate --pmc runs).
+    command (profiles/<summary_name>; collected with tools_diag/prof.sh in separate --pmc runs).
     FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
     coalesced reads at 64 bytes, so it is doubled."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", summary_name)

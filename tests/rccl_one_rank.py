@@ -16,6 +16,7 @@ from long_vita_amd.ring_context_parallel import TorchDistComm, RingAttention  # 
 from long_vita_amd import ops  # noqa: E402
 
 comm = TorchDistComm(dist.group.WORLD, dev)
+second = dist.new_group([0])        # a second "nccl" communicator, as --use-cp-send-recv-overlap sets one up
 g = torch.Generator(device=dev).manual_seed(3)
 S, HQ, HKV, D = 8192, 10, 2, 128
 q = torch.randn(S, HQ, D, generator=g, device=dev).to(torch.bfloat16)
@@ -30,6 +31,19 @@ for rep in range(3):
     assert torch.equal(kv[0], kv[1]), "received block differs"
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
     kv[1].zero_()
+# a grouped send + receive on ONE communicator from a rank to itself matches; split over two communicators the send on
+# the first would wait for a receive on the first that nobody posts.  What one rank can exercise of the split form is
+# each communicator and each lane on its own: K / V on lane 0 through the first group while an fp32 block goes through
+# the second group on lane 1, both under a block kernel.
+f32 = [torch.randn(2, S, HKV, D, generator=g, device=dev), torch.zeros(2, S, HKV, D, device=dev)]
+lane1 = TorchDistComm(second, dev)
+h0 = comm.exchange([kv[0]], [kv[1]], 0, 0, lane=0)
+h1 = lane1.exchange([f32[0]], [f32[1]], 0, 0, lane=1)
+out, lse = ops.attn_fwd_launch(q, kv[0][0], kv[0][1], desc, D ** -0.5, True)
+comm.wait(h0)
+lane1.wait(h1)
+torch.cuda.synchronize()
+assert torch.equal(kv[0], kv[1]) and torch.equal(f32[0], f32[1]), "two communicators, two lanes: received blocks differ"
 dist.barrier()
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)

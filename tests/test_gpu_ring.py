@@ -131,7 +131,7 @@ def test_transport_on_the_rccl_backend_one_rank():
     assert res.returncode == 0 and "rccl self-exchange ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len):
+def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len, overlap=False):
     """One CP rank of the entry-point test: ambient state as Megatron / MindSpeed would hold it, the batch cut by
     get_batch_on_this_cp_rank, attention through flash_attention_forward, results reassembled by sync_output."""
     import os
@@ -146,9 +146,11 @@ def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len):
     from long_vita_amd import cp_partition, state
     from long_vita_amd.core_attention import flash_attention_forward
     packed = actual_seq_len is not None
-    state.mpu.initialize(dist.group.WORLD, world, rank)
+    # --use-cp-send-recv-overlap: a second communicator over the same ranks (dot_product_attention.py:59-60)
+    over_group = dist.new_group(list(range(world))) if overlap else None
+    state.mpu.initialize(dist.group.WORLD, world, rank, overlap_group=over_group)
     state.set_args(state.make_args(context_parallel_size=world, seq_length=S, reset_attention_mask=packed,
-                                   reset_position_ids=packed))
+                                   reset_position_ids=packed, use_cp_send_recv_overlap=overlap))
     state.set_actual_seq_len(actual_seq_len)
     g = torch.Generator().manual_seed(23)
     q = torch.randn(S, 1, Hq, D, generator=g).to(torch.bfloat16)
@@ -168,6 +170,9 @@ def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len):
     assert out.shape == (S // world, 1, Hq * D)
     out.backward(batch["do"].transpose(0, 1))
     torch.cuda.synchronize()
+    from long_vita_amd.ring_context_parallel import _engines
+    (eng,) = _engines.values()
+    assert eng.overlap_group is over_group and eng.comm.overlap_group is over_group
     # sync_output gathers [b, s_local, ...] over the CP group and undoes the zig-zag (tasks/.../utils.py:557-581)
     whole = {name: cp_partition.sync_output(t.detach().transpose(0, 1).contiguous().cpu())[0]
              for name, t in (("out", out), ("dq", ql.grad.flatten(2)), ("dk", kl.grad.flatten(2)), ("dv", vl.grad.flatten(2)))}
@@ -190,16 +195,17 @@ def _entry_worker(rank, world, port, S, Hq, Hkv, D, actual_seq_len):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("actual_seq_len", [None, [300, 301, 1500, 2048]], ids=["causal", "packed"])
-def test_cp_branches_through_flash_attention_forward_two_processes(actual_seq_len):
+@pytest.mark.parametrize("actual_seq_len,overlap", [(None, False), ([300, 301, 1500, 2048], False), (None, True)],
+                         ids=["causal", "packed", "causal_send_recv_overlap_group"])
+def test_cp_branches_through_flash_attention_forward_two_processes(actual_seq_len, overlap):
     """The context-parallel branches of the patched entry point (dot_product_attention.py:374-379 generic causal,
     :339-343 reset_attention_mask + actual_seq_len) end to end in two processes: state.mpu -> cp_para ->
     ringattn_context_parallel -> HIP ring, forward and backward, inputs cut by get_batch_on_this_cp_rank and results
     reassembled by sync_output's all_gather, against the oracle on the whole sequence."""
     import os
     import torch.multiprocessing as mp
-    port = 35500 + (os.getpid() % 2000) + (0 if actual_seq_len is None else 1)
-    mp.spawn(_entry_worker, args=(2, port, 2048, 10, 2, 128, actual_seq_len), nprocs=2, join=True)
+    port = 35500 + (os.getpid() % 2000) + (0 if actual_seq_len is None else 1) + (2 if overlap else 0)
+    mp.spawn(_entry_worker, args=(2, port, 2048, 10, 2, 128, actual_seq_len, overlap), nprocs=2, join=True)
 
 
 class _FeedComm:

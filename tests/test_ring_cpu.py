@@ -168,32 +168,41 @@ def test_segment_rects_exact_cover_on_random_packings():
         assert (cover == want).all(), (trial, cp, c, cu)
 
 
-def _gloo_worker(rank, world, port, S, Hq, Hkv, D, scale, out_dir):
+def _gloo_worker(rank, world, port, S, Hq, Hkv, D, scale, out_dir, overlap=False):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from long_vita_amd.ring_context_parallel import ringattn_context_parallel, _engines, RingAttention
+    from long_vita_amd.ring_context_parallel import ringattn_context_parallel, _engines, _engine_for, RingAttention
+    # the second communicator of --use-cp-send-recv-overlap (dot_product_attention.py:59-60): sends and receives split
+    over_group = dist.new_group(list(range(world))) if overlap else None
     q, k, v, do = _problem(S, Hq, Hkv, D)
     ql, kl, vl, dl = (zigzag_local(x, world, rank).reshape(S // world, 1, -1).clone() for x in (q, k, v, do))
     ql.requires_grad_(True); kl.requires_grad_(True); vl.requires_grad_(True)
     cp_para = dict(causal=True, cp_group=dist.group.WORLD, cp_size=world, rank=rank, cp_global_ranks=list(range(world)),
-                   cp_group_for_send_recv_overlap=None, pse=None, pse_type=None)
+                   cp_group_for_send_recv_overlap=over_group, pse=None, pse_type=None)
     # inject the checker backend into the engine the public entry point will create
-    key = (id(dist.group.WORLD), world, rank, True, tuple(range(world)))
-    _engines[key] = RingAttention(dist.group.WORLD, world, rank, True, list(range(world)), backend=CheckerBackend())
+    eng = _engine_for(dist.group.WORLD, over_group, world, rank, True, list(range(world)))
+    eng.backend = CheckerBackend()
+    assert list(_engines) == [(tuple(range(world)), world, rank, True, tuple(range(world)))]
     out = ringattn_context_parallel(ql, kl, vl, Hq, cp_para, scale, None, 0.)
     out.backward(dl)
+    assert len(_engines) == 1 and _engine_for(dist.group.WORLD, over_group, world, rank, True, list(range(world))) is eng
+    assert (eng._comm(ql.device).overlap_group is over_group) and eng.workspace_bytes() > 0
+    # a group made again with the same ranks must not inherit the engine of the old one
+    other = dist.new_group(list(range(world)))
+    assert _engine_for(other, None, world, rank, True, list(range(world))) is not eng and eng.workspace_bytes() == 0
     torch.save({"out": out.detach(), "dq": ql.grad, "dk": kl.grad, "dv": vl.grad}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ring_gloo_world2(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True], ids=["one_group", "send_recv_overlap_group"])
+def test_ring_gloo_world2(tmp_path, overlap):
     S, Hq, Hkv, D, scale, world = 48, 4, 2, 8, 0.25, 2
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_gloo_worker, args=(world, port, S, Hq, Hkv, D, scale, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + (2000 if overlap else 0)
+    mp.spawn(_gloo_worker, args=(world, port, S, Hq, Hkv, D, scale, str(tmp_path), overlap), nprocs=world, join=True)
     q, k, v, do = _problem(S, Hq, Hkv, D)
     ref_o, _ = A.varlen_attention(q, k, v, [0, S], scale)
     rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, [0, S], scale)

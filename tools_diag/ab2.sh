@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of library builds by plain bench runs: tools_ab2.sh "<bench args>" <lib1> <lib2> ...
+# Same-box A/B of library builds by plain bench runs: tools_diag/ab2.sh "<bench args>" <lib1> <lib2> ...
 ARGS=$1; shift
 L=long-vita_amd/liblvattn.so
 cp $L /tmp/lv_orig.so

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of library builds x kernel selections: tools_ab3.sh "<bench args>" "<lib:kernel:waves> ..." [rounds]
+# Same-box A/B of library builds x kernel selections: tools_diag/ab3.sh "<bench args>" "<lib:kernel:waves> ..." [rounds]
 ARGS=$1; VARS=$2; ROUNDS=${3:-2}
 L=long-vita_amd/liblvattn.so
 cp $L /tmp/lv_orig.so

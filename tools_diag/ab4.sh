@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of library builds x LVATTN_DKDV_UNITS: tools_ab4.sh "<bench args>" "<lib:units> ..." [rounds]
+# Same-box A/B of library builds x LVATTN_DKDV_UNITS: tools_diag/ab4.sh "<bench args>" "<lib:units> ..." [rounds]
 ARGS=$1; VARS=$2; ROUNDS=${3:-2}
 L=long-vita_amd/liblvattn.so
 cp $L /tmp/lv_orig.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over the default bench (1M-token prefill on one GPU); run on the GPU box from
-# the repo root:  bash tools_prof.sh <tag> [extra bench args]
+# the repo root:  bash tools_diag/prof.sh <tag> [extra bench args]
 # Pass 1: kernel trace + stats.  Passes 2-4: PMC counters, each in a run of its own
 # (TRACE_ONLY=1 stops after pass 1).
 TAG=${1:-x}; shift

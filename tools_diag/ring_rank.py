@@ -4,7 +4,7 @@ would in a CP group, the exchange is replaced by a local copy on the side stream
 structure, no fabric).  With --rccl the copy is a real RCCL send + receive of the block from this one rank to itself
 (process group "nccl", world size 1), posted by the shipped transport class: the RCCL kernel then competes with the
 block kernel for the GPU as it would on a node, only its bytes stay in local memory.
-Usage: python tools_ring_rank.py [--cp 8] [--seq 1048576] [--ranks 0,7] [--bwd] [--rccl]"""
+Usage: python tools_diag/ring_rank.py [--cp 8] [--seq 1048576] [--ranks 0,7] [--bwd] [--rccl]"""
 import argparse
 import math
 import os
@@ -13,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from long_vita_amd.ring_context_parallel import RingAttention  # noqa: E402
 
 HQ, HKV, D = 40, 8, 128
@@ -45,8 +45,8 @@ def self_rccl_comm(dev):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     class SelfComm(TorchDistComm):      # every virtual neighbour is this rank
-        def exchange(self, send_bufs, recv_bufs, dst, src):
-            return super().exchange(send_bufs, recv_bufs, 0, 0)
+        def exchange(self, send_bufs, recv_bufs, dst, src, lane=0):
+            return super().exchange(send_bufs, recv_bufs, 0, 0, lane)
     return SelfComm(dist.group.WORLD, dev)
 
 
