@@ -160,8 +160,12 @@ int lvattn_decode(const void* q, const void* k, const void* v, void* out, float*
  * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  Same arguments and results as lvattn_decode minus the workspace.  Returns LV_ESIZE when
  * batch * hkv * n_split * (hq / hkv) * (d + 1) * 4 bytes exceed the buffer (pass a smaller n_split or use
- * lvattn_decode); the 40 / 8-head, d = 128 shape fits up to batch 6 at the default split.  All calls on one GPU
- * share the buffer: calls that overlap on one GPU (two streams, two threads) race and must be serialised by the
+ * lvattn_decode).  For 40 / 8 heads at d = 128 that is batch * n_split <= 406; the default split keeps
+ * batch * hkv * n_split near 512 (n_split = ceil(512 / (batch * hkv)), at least 1), i.e. about 1.3 MiB of partial
+ * results, so the default fits at any batch up to 406 and only an explicit large n_split overflows.
+ * The first call on each GPU looks the buffer's device address up (hipGetSymbolAddress, which may load the code
+ * object): make that first call OUTSIDE stream capture; later calls on that GPU are capture-safe.  All calls on one
+ * GPU share the buffer: calls that overlap on one GPU (two streams, two threads) race and must be serialised by the
  * caller. */
 int64_t lvattn_decode_noalloc_max_bytes(void);
 int lvattn_decode_noalloc(const void* q, const void* k, const void* v, void* out, float* lse,
@@ -270,7 +274,9 @@ int lv_rope(const void* x, void* out, const void* cos_tab, const void* sin_tab, 
  * scripts/modellink/qwen25/finetune_qwen25_14b_intern_300m_ptd_tp8pp1_stage4.sh:164, removes the same pass on the NPU):
  *  - lvattn_fwd_rope = lvattn_fwd on UNROTATED queries: each workgroup rotates its query rows in registers as it
  *    loads them (same tables, table-row rule and bf16 roundings as lv_rope with rot == d, so the result equals
- *    lvattn_fwd on lv_rope(q) bit for bit); k must already be rotated.  q_rot (optional, [q rows, hq, d] bf16 with
+ *    lvattn_fwd on lv_rope(q) bit for bit when that launch runs the ping-pong kernel too; lvattn_fwd's default for key
+ *    sweeps of 32,768 and more is the one-wave kernel, which has no rotation and rounds differently, a few 1e-3
+ *    relative); k must already be rotated.  q_rot (optional, [q rows, hq, d] bf16 with
  *    strides) receives the rotated queries for the backward pass.  Head dim 128 only.
  *  - lv_rope_pack_kv rotates K while packing K and V into the ring's message buffer kv [2, rows, heads, d]
  *    (contiguous): kv[0] = lv_rope(k), kv[1] = v -- one pass instead of a rotation and two copies. */

@@ -359,7 +359,10 @@ static int decode_impl(const char* who, const void* q, const void* k, const void
                        int64_t q_bs, int64_t q_hs, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                        int64_t v_bs, int64_t v_rs, int64_t v_hs, int64_t o_bs, int64_t o_hs,
                        float scale, int n_split, void* stream, bool library_scratch) {
-    if (int e = check_common(q, k, v, hq, hkv, d, q_bs, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
+    // q is [batch, hq, d]: its batch stride is no tile row stride (the kernel forms q's offsets in 64 bits), so it only
+    // has to be a multiple of 8 elements; the 256-row tile cap of the prefill kernels applies to the K / V row strides
+    if (q_bs < 0 || (q_bs & 7)) return fail(LV_EINVAL, "%s: q batch stride %lld must be a non-negative multiple of 8 elements", who, (long long)q_bs);
+    if (int e = check_common(q, k, v, hq, hkv, d, 0, q_hs, k_rs, k_hs, v_rs, v_hs)) return e;
     if (!out || (!workspace && !library_scratch)) return fail(LV_EINVAL, "%s: null out/workspace pointer", who);
     if (batch <= 0 || k_len <= 0) return fail(LV_EINVAL, "%s: batch=%d k_len=%d", who, batch, k_len);
     if (hq / hkv > 32) return fail(LV_EINVAL, "%s: %d query heads per KV head (at most 32)", who, hq / hkv);

@@ -691,8 +691,9 @@ def _check_rope_tables(cos_tab, sin_tab, pos_ids, rows: int, who: str):
 def attn_fwd_rope_launch(q, k_rot, v, desc: torch.Tensor, scale: float, causal: bool, cos_tab, sin_tab, pos_ids=None,
                          tab_div: int = 1, out=None, lse=None, q_rot=None):
     """``attn_fwd_launch`` on UNROTATED queries: the kernel rotates each query row in registers as it loads it (tables
-    and table-row rule of ``rope_launch``, rot == d == 128), so the result equals attn_fwd_launch(rope(q), k_rot, v) bit
-    for bit without the rotated queries ever going through memory.  ``k_rot`` must already be rotated.  ``q_rot``
+    and table-row rule of ``rope_launch``, rot == d == 128), so the result equals attn_fwd_launch(rope(q), k_rot, v) on the
+    ping-pong kernel bit for bit without the rotated queries ever going through memory (a plain launch that takes the
+    one-wave kernel -- the default for key sweeps of 32,768 and more -- differs by kernel rounding).  ``k_rot`` must already be rotated.  ``q_rot``
     (optional, bf16 [rows, hq, d]) receives the rotated queries (the backward kernels read them)."""
     q, k_rot, v = _last_contig(q), _last_contig(k_rot), _last_contig(v)
     _check_qkv(q, k_rot, v)
@@ -780,7 +781,9 @@ def rope_varlen_attention(q, k, v, cos_tab, sin_tab, cu_seqlens: Sequence[int], 
     """varlen_attention(rope(q), rope(k), v) with the query rotation folded into the attention kernel (head dim 128,
     rotary width 128).  q [T,Hq,128], k/v [T,Hkv,128] bf16 UNROTATED; cos_tab / sin_tab [tab_rows, 128] bf16; table row
     of token t = pos_ids[t] (int32) or t // tab_div.  Returns (out, lse); differentiable in q, k, v, and every result
-    (out, lse, dq, dk, dv) is bit-identical to the unfused sequence rope -> varlen_attention."""
+    (out, lse, dq, dk, dv) is bit-identical to the unfused sequence rope -> varlen_attention run on the SAME forward kernel
+    (the rotation lives in the ping-pong kernel; a plain launch whose work items sweep 32,768 keys or more takes the
+    one-wave kernel by default and then differs from the fused result by kernel rounding, a few 1e-3 relative)."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     return _RopeVarlenAttention.apply(q, k, v, cos_tab, sin_tab, pos_ids, int(tab_div), tuple(int(x) for x in cu_seqlens),

@@ -542,7 +542,8 @@ def ringattn_context_parallel(q, k, v, n, cp_para, softmax_scale=None, attn_mask
     ``rope`` = (cos, sin) (not in the reference's signature: its rotary embedding is applied by the caller, with the
     scripts' --use-fused-rotary-pos-emb by a fused NPU op): bf16 tables [s_local, d] for THIS rank's rows
     (rotary_pos_embedding.py:36-47); q and k then come UNROTATED and the rotation happens inside the ring
-    (differentiable; results bit-identical to rotating first)."""
+    (differentiable; results bit-identical to rotating first when both run the ping-pong forward kernel, within kernel
+    rounding of it where the plain ring picks the one-wave kernel for long blocks)."""
     if dropout_p not in (0, 0.0):
         raise NotImplementedError("attention dropout is not supported on the ring path (the shipped scripts use 0)")
     if cp_para.get("pse") is not None:

@@ -146,7 +146,8 @@ def rope_flash_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Te
     (already gathered by position ids / sliced for the CP rank as RotaryEmbedding.forward leaves them, :114-121) ->
     [s, 1, Hq*128].  ``actual_seq_len`` = cumulative END offsets of packed segments (None: one causal segment).
     The keys are rotated by the bandwidth-bound kernel, the queries inside the attention kernel; results and gradients
-    are bit-identical to apply_rotary_pos_emb + flash_attention_forward on this package's kernels."""
+    are bit-identical to apply_rotary_pos_emb + flash_attention_forward on this package's ping-pong forward kernel, and
+    within kernel rounding of them where the plain path picks the one-wave kernel (key sweeps of 32,768 and more)."""
     _check(query, False)
     s, b, hq, d = query.shape
     if b != 1:

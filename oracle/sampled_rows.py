@@ -22,7 +22,7 @@ import torch
 def row_stats(q, k, v, do, heads, seg, rows, scale: float, chunk: int = 2048):
     """float64 log-sum-exp and delta = <dO_i, O_i> of the causal rows ``rows`` = (r0, r1) of segment ``seg`` = (a, b)
     (a <= r0 < r1 <= b, global row indices) for the query heads ``heads``.  q/do [T, Hq, D], k/v [T, Hkv, D].
-    Returns (lse, delta), each [len(heads), r1 - r0]."""
+    Returns (lse, delta), each [len(heads), r1 - r0].  (``saved_delta`` gives the other delta: from a SAVED output.)"""
     a, b = seg
     r0, r1 = rows
     rep = q.shape[1] // k.shape[1]
@@ -45,8 +45,18 @@ def row_stats(q, k, v, do, heads, seg, rows, scale: float, chunk: int = 2048):
     return lse, delta
 
 
-def dq_row(q, k, v, do, i: int, h: int, seg, scale: float):
-    """float64 dq[i, h] ([D]) of the causal segment ``seg`` = (a, b) that holds row i; also returns (lse, out_row)."""
+def saved_delta(out, do, heads, rows):
+    """delta = <dO_i, O_i> from a SAVED forward output ``out`` [T, Hq, D] (what a fused backward reads: the forward's
+    result in its storage precision, here bf16) instead of the exact float64 O: [len(heads), r1 - r0].  The two deltas
+    differ by the rounding of O; on a short row with one dominant key, where dP - delta nearly cancels, that rounding
+    is most of the row's gradient error, so the tight per-row comparisons use this one."""
+    r0, r1 = rows
+    return torch.stack([(out[r0:r1, h].double() * do[r0:r1, h].double()).sum(-1) for h in heads])
+
+
+def dq_row(q, k, v, do, i: int, h: int, seg, scale: float, out_saved=None):
+    """float64 dq[i, h] ([D]) of the causal segment ``seg`` = (a, b) that holds row i; also returns (lse, out_row).
+    With ``out_saved`` [T, Hq, D], delta comes from that saved output row instead of the exact one."""
     a, _ = seg
     g = h // (q.shape[1] // k.shape[1])
     kk, vv = k[a:i + 1, g].double(), v[a:i + 1, g].double()
@@ -55,7 +65,8 @@ def dq_row(q, k, v, do, i: int, h: int, seg, scale: float):
     p = torch.exp(s - l)
     o = p @ vv
     d_o = do[i, h].double()
-    ds = p * (vv @ d_o - (d_o * o).sum())
+    delta = (d_o * (o if out_saved is None else out_saved[i, h].double())).sum()
+    ds = p * (vv @ d_o - delta)
     return (ds @ kk) * scale, l, o
 
 

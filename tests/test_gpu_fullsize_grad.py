@@ -27,30 +27,52 @@ def _rnd(dev, seed):
     return lambda *shape: (torch.randn(*shape, generator=g, device=dev) * 0.5).to(torch.bfloat16)
 
 
-def _check_rows(tag, q, k, v, do, lse, dq, dk, dv, seg, groups, q_rows, k_rows, scale, stats_from=None):
-    """Sampled rows of one causal segment against float64.  Returns the largest row_excess seen per tensor."""
+def _two_bounds(got, exact, saved, tensor_max):
+    """(tight, stated) excess of one gradient row.  tight: against float64 with delta from the saved bf16 output (what a
+    fused backward reads), floor relative to the ROW's own largest element.  stated: against the exact float64 gradient
+    under the project's per-element tolerance, whose absolute floor is relative to the TENSOR's largest element
+    (5e-3 max|tensor|; tests/test_gpu_attention.py ``elementwise_excess``)."""
+    return (R.row_excess(got, saved, tiny=1e-4 * tensor_max), R.row_excess(got, exact, floor=0.0, tiny=5e-3 * tensor_max))
+
+
+def _check_rows(tag, q, k, v, do, out, lse, dq, dk, dv, seg, groups, q_rows, k_rows, scale, stats_from=None):
+    """Sampled rows of one causal segment against float64.  Returns the largest excess seen per tensor and bound."""
     a, b = seg
     rep = q.shape[1] // k.shape[1]
-    worst = {"dq": 0.0, "dk": 0.0, "dv": 0.0, "lse": 0.0}
-    tiny = 1e-4 * float(dq.float().abs().max())      # for rows whose exact gradient is zero (a segment's first row)
+    worst = {"dq": [0.0, 0.0], "dk": [0.0, 0.0], "dv": [0.0, 0.0], "lse": 0.0}
+    tmax = {"dq": float(dq.float().abs().max()), "dk": float(dk.float().abs().max()), "dv": float(dv.float().abs().max())}
+
+    def note(name, row, pair):
+        if max(pair) > 0.7:
+            print(f"  {tag}: {name} row {row}: excess tight {pair[0]:.3f} stated {pair[1]:.3f}", flush=True)
+        worst[name] = [max(x, y) for x, y in zip(worst[name], pair)]
     for g in groups:
         heads = list(range(g * rep, g * rep + rep))
         for i in q_rows:
             for h in (heads[0], heads[-1]):
-                ref, l, _ = R.dq_row(q, k, v, do, i, h, seg, scale)
-                worst["dq"] = max(worst["dq"], R.row_excess(dq[i, h], ref, tiny=tiny))
+                exact, l, _ = R.dq_row(q, k, v, do, i, h, seg, scale)
+                saved, _, _ = R.dq_row(q, k, v, do, i, h, seg, scale, out_saved=out)
+                note("dq", (i, h), _two_bounds(dq[i, h], exact, saved, tmax["dq"]))
                 worst["lse"] = max(worst["lse"], abs(float(lse[h, i]) - float(l)))
         r0 = a if stats_from is None else stats_from
         st_lse, st_delta = R.row_stats(q, k, v, do, heads, seg, (r0, b), scale)
+        sv_delta = R.saved_delta(out, do, heads, (r0, b))
         worst["lse"] = max(worst["lse"], float((lse[heads, r0:b].double() - st_lse).abs().max()))
         for j in k_rows:
             assert j >= r0
-            rdk, rdv = R.dkdv_row(q, k, v, do, j, g, seg, st_lse, st_delta, r0, scale)
-            worst["dk"] = max(worst["dk"], R.row_excess(dk[j, g], rdk))
-            worst["dv"] = max(worst["dv"], R.row_excess(dv[j, g], rdv))
-        del st_lse, st_delta
-    print(f"{tag}: worst row excess {worst}", flush=True)
+            edk, edv = R.dkdv_row(q, k, v, do, j, g, seg, st_lse, st_delta, r0, scale)
+            sdk, sdv = R.dkdv_row(q, k, v, do, j, g, seg, st_lse, sv_delta, r0, scale)
+            note("dk", (j, g), _two_bounds(dk[j, g], edk, sdk, tmax["dk"]))
+            note("dv", (j, g), _two_bounds(dv[j, g], edv, sdv, tmax["dv"]))
+        del st_lse, st_delta, sv_delta
+    print(f"{tag}: worst row excess [tight, stated] {worst}", flush=True)
     return worst
+
+
+def _assert_rows(w, what):
+    for name in ("dq", "dk", "dv"):
+        assert w[name][0] <= 1.0 and w[name][1] <= 1.0, (what, name, w)
+    assert w["lse"] <= LSE_TOL, (what, w)
 
 
 def test_cfg3_single_segment_gradient_rows_against_float64():
@@ -67,10 +89,9 @@ def test_cfg3_single_segment_gradient_rows_against_float64():
     out.backward(do)
     torch.cuda.synchronize()
     rows = [0, 1, 127, 128, 255, 256, 4095, 65535, 65536, 100000, S - 129, S - 128, S - 2, S - 1]
-    w = _check_rows("cfg3-A", q.detach(), k.detach(), v.detach(), do, lse, q.grad, k.grad, v.grad, (0, S), (0, Hkv - 1),
-                    rows, rows, scale)
-    assert w["dq"] <= 1.0 and w["dk"] <= 1.0 and w["dv"] <= 1.0, w
-    assert w["lse"] <= LSE_TOL, w
+    w = _check_rows("cfg3-A", q.detach(), k.detach(), v.detach(), do, out.detach(), lse, q.grad, k.grad, v.grad, (0, S),
+                    (0, Hkv - 1), rows, rows, scale)
+    _assert_rows(w, "cfg3-A")
 
 
 def test_cfg3_packed_gradient_rows_against_float64():
@@ -101,10 +122,9 @@ def test_cfg3_packed_gradient_rows_against_float64():
         a, b = segs[si]
         L = b - a
         rows = sorted({a, a + 1, a + min(127, L - 1), a + min(128, L - 1), a + L // 2, b - 1 - (L - 1) % 128, b - 2, b - 1})
-        w = _check_rows(f"cfg3-B segment {si} [{a}, {b})", q.detach(), k.detach(), v.detach(), do, lse, q.grad, k.grad, v.grad,
-                        (a, b), (3,), rows, rows, scale)
-        assert w["dq"] <= 1.0 and w["dk"] <= 1.0 and w["dv"] <= 1.0, (si, w)
-        assert w["lse"] <= LSE_TOL, (si, w)
+        w = _check_rows(f"cfg3-B segment {si} [{a}, {b})", q.detach(), k.detach(), v.detach(), do, out.detach(), lse, q.grad,
+                        k.grad, v.grad, (a, b), (3,), rows, rows, scale)
+        _assert_rows(w, si)
 
 
 def _excess_on_device(got, ref, rtol=REL_TOL, floor=0.25):
@@ -138,31 +158,23 @@ def test_full_size_ring_backward_all_ranks_1m():
     torch.cuda.synchronize()
 
     # 1. the whole-context backward against float64 on sampled rows
-    worst = {"dq": 0.0, "dk": 0.0, "dv": 0.0, "lse": 0.0}
     g = 5
+    w = _check_rows("1M whole context, last 32K keys", q, k, v, do, whole, whole_lse, dq_all, dk_all, dv_all, (0, S), (g,),
+                    (0, 255, 256, 65535, 65536, 524287, 524288, 900001, S - 1),
+                    (S - 32768, S - 32768 + 127, S - 32768 + 128, S - 10000, S - 129, S - 128, S - 1), scale, stats_from=S - 32768)
+    _assert_rows(w, "1M last keys")
+    # early keys: every later row of the group's five heads contributes; float64 algebra on the forward's log-sum-exp
     heads = list(range(g * rep, g * rep + rep))
-    for i in (0, 255, 256, 65535, 65536, 524287, 524288, 900001, S - 1):
-        for h in (heads[0], heads[-1]):
-            ref, l, _ = R.dq_row(q, k, v, do, i, h, (0, S), scale)
-            worst["dq"] = max(worst["dq"], R.row_excess(dq_all[i, h], ref, tiny=1e-4 * float(dq_all[:65536].float().abs().max())))
-            worst["lse"] = max(worst["lse"], abs(float(whole_lse[h, i]) - float(l)))
-    r0 = S - 32768
-    st_lse, st_delta = R.row_stats(q, k, v, do, heads, (0, S), (r0, S), scale, chunk=1024)
-    worst["lse"] = max(worst["lse"], float((whole_lse[heads, r0:].double() - st_lse).abs().max()))
-    for j in (r0, r0 + 127, r0 + 128, S - 10000, S - 129, S - 128, S - 1):
-        rdk, rdv = R.dkdv_row(q, k, v, do, j, g, (0, S), st_lse, st_delta, r0, scale)
-        worst["dk"] = max(worst["dk"], R.row_excess(dk_all[j, g], rdk))
-        worst["dv"] = max(worst["dv"], R.row_excess(dv_all[j, g], rdv))
-    del st_lse, st_delta
     kernel_lse = whole_lse[heads].double()
-    kernel_delta = (whole[:, heads].double() * do[:, heads].double()).sum(-1).t().contiguous()
+    sv_delta = R.saved_delta(whole, do, heads, (0, S))
+    tmax_k, tmax_v = float(dk_all.float().abs().max()), float(dv_all.float().abs().max())
+    worst = [0.0, 0.0]
     for j in (0, 127, 128, 65536, 524288 - 1, 524288):
-        rdk, rdv = R.dkdv_row(q, k, v, do, j, g, (0, S), kernel_lse, kernel_delta, 0, scale)
-        worst["dk"] = max(worst["dk"], R.row_excess(dk_all[j, g], rdk))
-        worst["dv"] = max(worst["dv"], R.row_excess(dv_all[j, g], rdv))
-    del kernel_lse, kernel_delta
-    print(f"1M whole-context backward: worst row excess {worst}", flush=True)
-    assert worst["dq"] <= 1.0 and worst["dk"] <= 1.0 and worst["dv"] <= 1.0 and worst["lse"] <= LSE_TOL, worst
+        rdk, rdv = R.dkdv_row(q, k, v, do, j, g, (0, S), kernel_lse, sv_delta, 0, scale)
+        worst = [max(worst[0], R.row_excess(dk_all[j, g], rdk, tiny=1e-4 * tmax_k)), max(worst[1], R.row_excess(dv_all[j, g], rdv, tiny=1e-4 * tmax_v))]
+    del kernel_lse, sv_delta
+    print(f"1M whole-context backward, early keys: worst row excess dk {worst[0]:.3f} dv {worst[1]:.3f}", flush=True)
+    assert max(worst) <= 1.0, worst
 
     # 2. all eight ranks of the ring against it
     s_loc = S // cp

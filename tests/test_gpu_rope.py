@@ -177,6 +177,28 @@ def test_rotation_inside_the_attention_kernel_equals_the_two_pass_path(cu, kerne
     assert np.abs(lse_b.cpu().numpy() - ref_lse).max() <= 1e-3
 
 
+def test_fused_rotation_against_the_default_plain_path_on_a_long_sweep():
+    """A long single segment, where a plain launch takes the one-wave forward kernel by the library's own choice while
+    the fused launch stays on the ping-pong kernel (the rotation lives there): the two results are not bit-identical
+    (different kernels round differently) but agree to kernel rounding, outputs and log-sum-exp."""
+    from long_vita_amd import ops
+    S, HQ_, HKV_ = 65536, 2, 1
+    rs = np.random.RandomState(5)
+    ang = torch.from_numpy(R.angle_table(S, D, 1000000)).reshape(S, D)
+    cos_t, sin_t = torch.cos(ang).to(torch.bfloat16).cuda(), torch.sin(ang).to(torch.bfloat16).cuda()
+    q, k, v = (torch.from_numpy((0.5 * rs.randn(S, h, D)).astype(np.float32)).to(torch.bfloat16).cuda() for h in (HQ_, HKV_, HKV_))
+    scale = 1.0 / np.sqrt(128.0)
+    desc = ops.blocks_on_device([0, S], True, False, q.device)
+    assert desc.lv_mean_keys >= 32768                                   # the plain launch's default is the one-wave kernel
+    k_rot = ops.rope_launch(k, cos_t, sin_t)
+    plain, lse_p = ops.attn_fwd_launch(ops.rope_launch(q, cos_t, sin_t), k_rot, v, desc, scale, True)
+    fused, lse_f = ops.attn_fwd_rope_launch(q, k_rot, v, desc, scale, True, cos_t, sin_t)
+    torch.cuda.synchronize()
+    err = (fused.float() - plain.float()).abs().max().item() / plain.float().abs().max().item()
+    assert err <= 1e-2, err
+    assert (lse_f - lse_p).abs().max().item() <= 1e-4
+
+
 def test_rope_pack_kv_and_packed_positions(golden_dir):
     """kv[0] = rope(k) bit-exact against the reference-made fixture (packed position ids), kv[1] = v, from strided
     inputs in one pass."""

@@ -219,10 +219,14 @@ def test_sampled_gradient_rows_equal_the_full_float64_backward():
                 dq, l, o = R.dq_row(q, k, v, do, i, h, (a, b), scale)
                 assert np.abs(dq.numpy() - rdq[i, h]).max() < 1e-12 and abs(float(l) - rl[h, i]) < 1e-12
                 assert np.abs(o.numpy() - ro[i, h]).max() < 1e-12
+                dq2, _, _ = R.dq_row(q, k, v, do, i, h, (a, b), scale, out_saved=torch.from_numpy(ro))   # the exact output "saved"
+                assert np.abs(dq2.numpy() - rdq[i, h]).max() < 1e-12
         for gkv in range(Hkv):
             r0 = a + (b - a) // 3                                  # statistics from a row inside the segment onwards
             lse, delta = R.row_stats(q, k, v, do, list(range(gkv * rep, gkv * rep + rep)), (a, b), (r0, b), scale, chunk=50)
             assert np.abs(lse.numpy() - rl[gkv * rep:gkv * rep + rep, r0:b]).max() < 1e-12
+            sv = R.saved_delta(torch.from_numpy(ro), do, list(range(gkv * rep, gkv * rep + rep)), (r0, b))
+            assert float((sv - delta).abs().max()) < 1e-12
             for j in {r0, (r0 + b) // 2, b - 1}:
                 dk, dv = R.dkdv_row(q, k, v, do, j, gkv, (a, b), lse, delta, r0, scale)
                 assert np.abs(dk.numpy() - rdk[j, gkv]).max() < 1e-12 and np.abs(dv.numpy() - rdv[j, gkv]).max() < 1e-12
