@@ -129,9 +129,14 @@ int lvattn_fwd_hinted(const void* q, const void* k, const void* v, void* out, fl
 /* Host side, pure CPU: the mean key count per descriptor of a table the builders above wrote (-1 for an empty table). */
 int lv_mean_keys_per_item(const int32_t* desc_host, int n_blocks);
 
-/* Tuning / test hook, no counterpart in the reference: choose the forward kernel for later lvattn_fwd calls of this
- * process ("default", "a4", "pp", "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which
- * is read on first use otherwise).  Not thread-safe against concurrent launches. */
+/* TEST HOOKS, NOT FOR PRODUCTION (no counterpart in the reference).  The two selectors below set process-global,
+ * unsynchronised state: they exist so that the test-suite can force every kernel variant through the same entry
+ * points and so that A/B timing runs can compare variants inside one process.  A deployment leaves them alone (the
+ * library's own choice is the measured-best one per launch shape) and must not call them while launches are in
+ * flight on another thread.
+ * lvattn_select_fwd_kernel: the forward kernel for later lvattn_fwd calls of this process ("default", "a4", "pp",
+ * "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which is read on first use
+ * otherwise). */
 int lvattn_select_fwd_kernel(const char* name);
 /* The same for the backward: dq in {"default", "pp", "lockstep"}, dkdv in {"default", "rs" (role-split, two units per
  * iteration), "rs1" (one unit), "single"} -- LVATTN_DQ_KERNEL / LVATTN_DKDV_KERNEL / LVATTN_DKDV_UNITS otherwise. */

@@ -1,5 +1,5 @@
 """ctypes binding of liblvattn.so.  The library is built in-tree by
-``make -C long-vita_amd/csrc`` (or ``__graft_entry__.build()``); a missing or
+``make -C long_vita_amd/csrc`` (or ``__graft_entry__.build()``); a missing or
 unloadable library is a hard error: there is no CPU fallback."""
 from __future__ import annotations
 

@@ -3,12 +3,12 @@
 # tools_diag/probe_cycles.sh "<lib> ..." [seq]   -- run on the GPU box from the repo root
 LIBS=$1; SEQ=${2:-131072}
 R=$GRAFT_REPO_ROOT
-L=$R/long-vita_amd/liblvattn.so
+L=$R/long_vita_amd/liblvattn.so
 cp $L /tmp/lv_orig.so
 export TMPDIR=/tmp
 cd /tmp
 for lib in $LIBS; do
-  [ "$lib" = liblvattn.so ] && cp /tmp/lv_orig.so $L || cp $R/long-vita_amd/$lib $L
+  [ "$lib" = liblvattn.so ] && cp /tmp/lv_orig.so $L || cp $R/long_vita_amd/$lib $L
   rm -rf /tmp/pc_out
   timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc_out --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY TCC_HIT_sum TCC_MISS_sum -- python3 $R/bench.py ${BENCH_ARGS:---seq $SEQ} --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline > /tmp/pc.log 2>&1 || { cp /tmp/lv_orig.so $L; tail -5 /tmp/pc.log; exit 1; }
   python3 - "$lib" <<'PY'

@@ -1,4 +1,4 @@
-"""Diagnostic: phase timings of the role-split dK/dV kernel from a stamped build (long-vita_amd/lv_stamp.so)."""
+"""Diagnostic: phase timings of the role-split dK/dV kernel from a stamped build (long_vita_amd/lv_stamp.so)."""
 import ctypes, math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from long_vita_amd import ops, _lib
