@@ -182,7 +182,7 @@ def test_fused_rotation_against_the_default_plain_path_on_a_long_sweep():
     the fused launch stays on the ping-pong kernel (the rotation lives there): the two results are not bit-identical
     (different kernels round differently) but agree to kernel rounding, outputs and log-sum-exp."""
     from long_vita_amd import ops
-    S, HQ_, HKV_ = 65536, 2, 1
+    S, HQ_, HKV_, D = 65536, 2, 1, 128
     rs = np.random.RandomState(5)
     ang = torch.from_numpy(R.angle_table(S, D, 1000000)).reshape(S, D)
     cos_t, sin_t = torch.cos(ang).to(torch.bfloat16).cuda(), torch.sin(ang).to(torch.bfloat16).cuda()
