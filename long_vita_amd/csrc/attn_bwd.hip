@@ -633,12 +633,12 @@ static bool dq_pingpong() {
 
 // dK/dV kernel choice: the role-split kernel (attn_bwd_dkdv_rs.hip) unless the environment variable
 // LVATTN_DKDV_KERNEL=single asks for the one-wave-per-SIMD kernel in this file.
-static bool dkdv_role_split() {
+static int dkdv_choice() {   // 0 role-split (default), 1 the kernel in this file, 2 the gap-scheduled one-wave kernel (d = 128)
     if (g_dkdv_kernel < 0) {
         const char* e = getenv("LVATTN_DKDV_KERNEL");
-        g_dkdv_kernel = (e && !strcmp(e, "single")) ? 1 : 0;
+        g_dkdv_kernel = (e && !strcmp(e, "single")) ? 1 : (e && !strcmp(e, "g")) ? 2 : 0;
     }
-    return g_dkdv_kernel == 0;
+    return g_dkdv_kernel;
 }
 // run-time override of the two choices above: 0 default, 1 the kernel in this file, < 0 leave as it is
 void lv_select_bwd_kernels(int dq, int dkdv) {
@@ -649,7 +649,9 @@ void lv_select_bwd_kernels(int dq, int dkdv) {
 template <int D>
 static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 block(512);
-    if (p.n_blocks > 0 && dkdv_role_split()) {
+    if (p.n_blocks > 0 && dkdv_choice() == 2 && D == 128) {
+        lv_launch_bwd_dkdv_g(p, causal, accum, stream);
+    } else if (p.n_blocks > 0 && dkdv_choice() != 1) {
         lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);
     } else if (p.n_blocks > 0) {
         dim3 grid((unsigned)((int64_t)p.n_blocks * p.hkv));

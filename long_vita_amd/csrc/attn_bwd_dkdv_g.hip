@@ -1,0 +1,439 @@
+// dK / dV kernel of the attention backward for gfx950, "one wave per SIMD, gap-scheduled" form (head dim 128;
+// LVATTN_DKDV_KERNEL=g selects it).
+//
+// One workgroup = 4 waves = one 128-key block of one K/V head; wave w keeps the K and V fragments and the dK^T and dV^T
+// accumulators of ITS 32 keys (key on the lane) in the 512 registers a lone wave of a SIMD has, while the workgroup
+// sweeps "units" (a 32-row query slice of one query head of the group; slices last to first, heads inside), staged in
+// an LDS ring by direct global -> LDS loads.  Same arithmetic and accumulation order as the first-generation kernel of
+// attn_bwd.hip: S = Q K^T, P = exp2(c S - lse2), dV^T += dO^T P, dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS.
+//
+// What differs is the instruction stream.  A lone wave issues everything its SIMD runs, about one instruction per four
+// cycles, and a v_mfma_f32_32x32x16_bf16 keeps the matrix pipe busy for 32: an iteration (one unit, 32 MFMAs, ONE
+// workgroup barrier) is written as 32 "gaps", each holding its MFMA followed by a fixed share of the other work --
+// exponentials, dS, bf16 packing, the LDS fragment reads of later gaps, the staging requests -- and a scheduling
+// barrier after every gap keeps the compiler from packing the MFMAs together and the vector work behind them.
+// Software pipeline of iteration u:
+//   gaps  0- 7  dP(u)    = dO(u) V^T          | P(u) = exp2(c S(u) - lse2(u))   | read Q(u+1) rows, delta(u), dO^T(u)
+//   gaps  8-15  S(u+1)   = Q(u+1) K^T         | pack P(u); dS(u) = P (dP - delta)| read dO^T(u), Q^T(u)
+//   gaps 16-23  dV^T    += dO^T(u) P(u)       | dS(u), pack                      | read Q^T(u), dO(u+1) rows
+//   gaps 24-31  dK^T    += Q^T(u) dS(u)       | staging requests of unit u+5     | read dO(u+1) rows, lse2(u+1)
+// The loop is unrolled over the six ring slots, so every LDS address is a lane register plus an immediate.
+//
+// Register file, laid out by hand as in the one-wave forward kernel (attn_fwd_a4.hip): the accumulator half holds
+//   a[0:63] dV^T (tile mt at 16 mt)   a[64:127] dK^T   a[128:159] K fragments   a[160:191] V fragments
+//   a[192:223] Q rows of the next unit   a[224:255] dO rows of the current unit (both read from LDS straight into place)
+// and is touched only by the asm statements here (MFMAs naming those registers, ds_read_b128 into them, the epilogue);
+// the vector half (scores, P, dS, transposed fragments, row constants, addresses) is the compiler's.  Left to itself
+// the allocator does not split such a kernel over the two halves: the plain-builtin form of this loop spilled 583
+// registers.  The compiler neither counts nor pads what is inside an asm statement: LDS reads into the accumulator half
+// are waited for by counted s_waitcnt inside the MFMA statement that needs them, and the wait states (an MFMA result ->
+// a vector reader: 12; a vector write -> an MFMA operand: 2) hold by construction of the gap schedule (every such pair
+// is at least three gaps apart).
+#include "a4_asm.h"
+
+namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void g_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        g_static_for<I + 1, N>(f);
+    }
+}
+
+// accumulator register numbers
+__device__ constexpr int g_DV(int mt) { return 16 * mt; }
+__device__ constexpr int g_DK(int mt) { return 64 + 16 * mt; }
+__device__ constexpr int g_KF(int ks) { return 128 + 4 * ks; }
+__device__ constexpr int g_VF(int ks) { return 160 + 4 * ks; }
+__device__ constexpr int g_QA(int ks) { return 192 + 4 * ks; }
+__device__ constexpr int g_OA(int ks) { return 224 + 4 * ks; }
+
+// x (vector registers) = or += A fragment x B fragment, both in the accumulator half; WAIT >= 0: first let all but WAIT
+// LDS reads land
+template <int A, int B, bool FIRST, int WAIT>
+__device__ __forceinline__ void g_mfma_x(f32x16& x) {
+    if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%c0)" :: "i"(WAIT) : "memory");
+    if constexpr (FIRST)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(x) : "i"(A), "i"(A + 3), "i"(B), "i"(B + 3));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(x) : "i"(A), "i"(A + 3), "i"(B), "i"(B + 3));
+}
+
+// Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i or + 4 i; lds_dst in M0).  As asm so that the compiler
+// does not count them; completion is waited for by hand.
+__device__ __forceinline__ void g_dma16(a4_u32x4 rs, int voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void g_dma4(const float* g, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
+template <int A, int N>
+__device__ __forceinline__ void g_get(float* o) {
+    o[0] = a4_get<A>();
+    if constexpr (N > 1) g_get<A + 1, N - 1>(o + 1);
+}
+
+}  // namespace
+
+template <bool CAUSAL, bool ACCUM_F32>
+__global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
+    constexpr int D = 128;
+    constexpr int BQ = 32;             // query rows per unit
+    constexpr int KS = D / 16;         // 8
+    constexpr int MT = D / 32;         // 4
+    constexpr int ROWB = D * 2;
+    constexpr int CPR = D / 8;
+    constexpr int QTILE = BQ * ROWB;   // 8 KiB: a unit's Q (or dO) rows
+    constexpr int SLOTB = 2 * QTILE + 256;   // [Q rows][dO rows][32 lse, 32 delta f32]
+    constexpr int NBUF = 6;            // ring slots: units u-? .. u+5 around iteration u
+    constexpr int AHEAD = NBUF - 1;    // staging distance in units
+    constexpr int HALF = 3;            // slots per address register set (ds offsets are 16-bit)
+    constexpr int RPP = 64 / CPR;      // rows per 1-KiB piece: 4
+    constexpr int PPW = 4;             // pieces per wave per unit (16 pieces: 8 of Q, 8 of dO)
+
+    // The accumulator half belongs to the asm statements below: sixteen 16-register values of the accumulator class are
+    // declared here and kept alive to the end, so that the register allocator counts all 256 as occupied and parks
+    // nothing of its own there (which value it maps to which register does not matter: it never touches them).
+    f32x16 hold[16];
+    asm volatile("" : "=a"(hold[0]), "=a"(hold[1]), "=a"(hold[2]), "=a"(hold[3]), "=a"(hold[4]), "=a"(hold[5]), "=a"(hold[6]), "=a"(hold[7]),
+                      "=a"(hold[8]), "=a"(hold[9]), "=a"(hold[10]), "=a"(hold[11]), "=a"(hold[12]), "=a"(hold[13]), "=a"(hold[14]), "=a"(hold[15]));
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char* const lds0 = (lds_char*)smem;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // Workgroup i runs on XCD i % 8 (own L2 each): key blocks are dealt to the XCDs by KV head, as in the role-split kernel
+    const int unit_id = blockIdx.x;
+    if (unit_id >= p.n_blocks * p.hkv) return;
+    const int blk = unit_id / p.hkv;
+    const int kvh = unit_id % p.hkv;
+
+    const AttnDesc dsc = p.desc[blk];
+    const int k_row0 = dsc.a_row0, k_rows = dsc.a_rows;
+    const int q_row0 = dsc.b_row0, q_len = dsc.b_len;
+    const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
+    const int nslice = (q_len + BQ - 1) / BQ;
+    const int niter = nslice * p.group;
+
+    // ---- K / V fragments -> registers (B operands; this lane's key = 32 w + r)
+    const int kbase_w = 32 * w;
+    const int kj = kbase_w + r;
+    {
+        const int grow = k_row0 + (kj < k_rows ? kj : k_rows - 1);
+        const __bf16* kp = p.k + (int64_t)grow * p.k_rs + (int64_t)kvh * p.k_hs + 8 * h;
+        const __bf16* vp = p.v + (int64_t)grow * p.v_rs + (int64_t)kvh * p.v_hs + 8 * h;
+        a4_u32x4 f[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f[ks] = *reinterpret_cast<const a4_u32x4*>(kp + 16 * ks);
+        g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) { a4_put4<g_KF(decltype(I_)::value)>(f[decltype(I_)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) f[ks] = *reinterpret_cast<const a4_u32x4*>(vp + 16 * ks);
+        g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) { a4_put4<g_VF(decltype(I_)::value)>(f[decltype(I_)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // dV^T = dK^T = 0
+    a4_zero16<0>(); a4_zero16<16>(); a4_zero16<32>(); a4_zero16<48>(); a4_zero16<64>(); a4_zero16<80>(); a4_zero16<96>(); a4_zero16<112>();
+
+    // ---- staging of a unit: waves 0, 1 bring the Q rows, waves 2, 3 the dO rows; piece j of wave w is rows
+    // RPP (PPW (w & 1) + j) .. + RPP - 1.  The LDS image is XOR-swizzled inside each row; the LDS side of the transfer is
+    // lane-linear, so the swizzle goes on the source.
+    const bool w_is_do = (w >= 2);
+    const int64_t x_rs = w_is_do ? p.do_rs : p.q_rs;
+    const int64_t x_hs = w_is_do ? p.do_hs : p.q_hs;
+    const __bf16* const x_base = (w_is_do ? p.dout : p.q) + (int64_t)q_row0 * x_rs;
+    const int prow0 = RPP * PPW * (w & 1) + lane / CPR;
+    const int rows_last = q_len - (nslice - 1) * BQ;   // only the last slice (the first one requested) can be partial
+    int voff_full[PPW], voff_part[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = prow0 + RPP * j;
+        const int ch16 = lds_off128(row, lane % CPR) - row * ROWB;
+        voff_full[j] = row * (int)(x_rs * 2) + ch16;
+        voff_part[j] = min(row, rows_last - 1) * (int)(x_rs * 2) + ch16;   // rows past the end repeat the last valid one
+    }
+    const int c_part = min(r, rows_last - 1) - r;
+    int ld_sl = nslice - 1, ld_hg = 0, ld_n = 0;   // (slice, head) of the next request; requests so far
+    const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
+    const int64_t x_step_head = x_hs * 2;
+    const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
+    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31; ONE request per unit for the
+    // whole workgroup, made by wave (unit number mod 4): a direct-to-LDS request costs its wave far more issue time
+    // than an ordinary load, so it is not duplicated
+    const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
+    const int64_t c_step_head = p.lse_stride;
+    const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
+    // the request of one unit, in two parts so that they can sit in different gaps
+    auto dma_pieces = [&](int slot) __attribute__((always_inline)) {
+        const bool partial = (ld_sl == nslice - 1);
+        const int rows_valid = partial ? rows_last : BQ;
+        // the descriptor, word by word and said to be wave-uniform (left to itself the compiler does the 64-bit pointer
+        // arithmetic of the request stream in vector registers, which a buffer instruction cannot take)
+        const uint64_t xb = (uint64_t)(uintptr_t)ld_x;
+        a4_u32x4 rs;
+        rs[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb);
+        rs[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xb >> 32)) & 0xffffu;
+        rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((rows_valid - 1) * (int)(x_rs * 2) + ROWB));
+        rs[3] = 0x00020000u;
+        const uint32_t dst = lds_base + slot * SLOTB + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) g_dma16(rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
+    };
+    auto dma_consts_and_advance = [&](int slot) __attribute__((always_inline)) {
+        const bool partial = (ld_sl == nslice - 1);
+        if ((ld_n & 3) == w) g_dma4(ld_c + (partial ? c_part : 0), lds_base + slot * SLOTB + 2 * QTILE);
+        // past the last unit the stream stays where it is: the loop's unconditional requests re-fetch that unit (into
+        // slots nobody reads any more)
+        const bool adv = (++ld_n < niter);
+        const bool wrap = (ld_hg + 1 == p.group);
+        const int64_t xs = wrap ? x_step_slice : x_step_head, cs = wrap ? c_step_slice : c_step_head;
+        ld_x += adv ? xs : 0;
+        ld_c += adv ? cs : 0;
+        ld_hg = adv ? (wrap ? 0 : ld_hg + 1) : ld_hg;
+        ld_sl = (adv && wrap) ? ld_sl - 1 : ld_sl;
+    };
+
+    // ---- LDS read addresses: one register set for slots 0..2 and one for slots 3..5 (ds offsets are 16-bit); the slot and
+    // the operand (Q at +0, dO at +QTILE, constants at +2 QTILE) are immediates.  Row reads: the XOR swizzle acts on address
+    // bits 4..7 only and every slot starts on a multiple of 256 bytes, so fragment ks (chunk 2 ks + h) is the address of
+    // fragment 0 with ks XORed into bits 5..7.
+    uint32_t a_addr[2];
+    a_addr[0] = lds_base + (uint32_t)lds_off128(r, h);
+    a_addr[1] = a_addr[0] + HALF * SLOTB;
+    const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gl = (lane >> 4) & 1;
+    lds_char* t_ptr[2][MT][2];       // transposed reads (rows in accumulator order)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            t_ptr[0][mt][jh] = lds0 + lds_off128(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
+            t_ptr[1][mt][jh] = t_ptr[0][mt][jh] + HALF * SLOTB;
+        }
+    lds_char* c_ptr[2];              // row constants of rows 8 g + 4 h .. + 3: lse at +0, delta at +128
+    c_ptr[0] = lds0 + 2 * QTILE + 16 * h;
+    c_ptr[1] = c_ptr[0] + HALF * SLOTB;
+
+    const float c = p.scale_log2e;
+
+    // pipeline state carried from one iteration to the next (the dO rows of the current unit are in a[224:255])
+    f32x16 sv;            // S of the current unit until gap 7, of the next one from gap 8
+    f32x4 l4[4];          // the current unit's lse (natural log), rows 8 g + 4 h .. + 3
+
+    int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
+
+    // LDS reads issued after the read of Q-row fragment j (gap j / 2) and before the MFMA of gap 8 + j that needs it: the
+    // fragments after it (7 - j), the four delta reads of gaps 4-7, two transposed reads in each of the gaps 8 .. 7 + j;
+    // the wait leaves a margin of three for the order inside a gap, which is the compiler's
+    // (gap 8 + j: at most 8 + j reads may still be in flight).
+    // One iteration.  SLOT = u mod 6 fixes every ring slot at compile time.
+    auto iteration = [&](auto SLOT_) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(SLOT_)::value;
+        constexpr int NEXT = (SLOT + 1) % NBUF;
+        constexpr int DMAS = (SLOT + AHEAD) % NBUF;
+        constexpr int CS = SLOT / HALF, CO = (SLOT % HALF) * SLOTB;      // address set and byte offset of the current slot
+        constexpr int NS = NEXT / HALF, NO = (NEXT % HALF) * SLOTB;      // ... of the next unit's slot
+
+        const int i0 = c_sl * BQ;   // first query row of the unit, relative to q_row0
+        if (++c_hg == p.group) { c_hg = 0; --c_sl; }
+        const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+
+        // Everything older than the last three iterations' requests has landed (this wave's share of unit u+1); the
+        // barrier makes that true of every wave's share, and tells this wave that all waves are done with the slot of
+        // unit u-1, which this iteration's requests overwrite.  No LDS read is left in flight either (the dO rows and
+        // the lse of this unit were read at the end of the last iteration).
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(3 * PPW) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        bf16x8 trf[2 * MT];       // transposed fragments: dO^T (s2, mt) of this unit in gaps 8-23, then Q^T in gaps 16-31
+        f32x4 d4[4];              // delta of this unit
+        f32x16 dp;
+        float pv[16];
+        bf16x8 pf[2], dsf[2];
+
+        auto tr_read = [&](bf16x8& f, int set, int off, int mt) __attribute__((always_inline)) {
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[set][mt][0] + off));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[set][mt][1] + off));
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        };
+
+        g_static_for<0, 32>([&](auto K_) __attribute__((always_inline)) {
+            constexpr int k = decltype(K_)::value;
+            // ---- the MFMA of this gap
+            if constexpr (k < 8) {
+                g_mfma_x<g_OA(k), g_VF(k), k == 0, -1>(dp);
+            } else if constexpr (k < 16) {
+                g_mfma_x<g_QA(k - 8), g_KF(k - 8), k == 8, k>(sv);
+            } else if constexpr (k < 24) {
+                constexpr int j = k - 16, s2 = j / MT, mt = j % MT;
+                a4_mfma_o<g_DV(mt), -1>(trf[j], pf[s2]);
+            } else {
+                constexpr int j = k - 24, s2 = j / MT, mt = j % MT;
+                a4_mfma_o<g_DK(mt), -1>(trf[j], dsf[s2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its gap's fillers behind it
+
+            // ---- LDS reads
+            if constexpr (k < 4) {                  // Q rows of unit u+1 -> a[192:223], two fragments per gap
+                a4_read_k<g_QA(2 * k), NO>(a_addr[NS] ^ (uint32_t)((2 * k) << 5));
+                a4_read_k<g_QA(2 * k + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * k + 1) << 5));
+            } else if constexpr (k < 8) {           // delta of unit u
+                d4[k - 4] = *(LDS_PTR(f32x4, c_ptr[CS] + CO + 128 + 32 * (k - 4)));
+            } else if constexpr (k < 16) {          // dO^T of unit u, fragment k - 8, needed in gap 16 + (k - 8)
+                constexpr int j = k - 8, s2 = j / MT, mt = j % MT;
+                tr_read(trf[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
+            } else if constexpr (k < 24) {          // Q^T of unit u, fragment k - 16, needed in gap 24 + (k - 16): into the
+                constexpr int j = k - 16, s2 = j / MT, mt = j % MT;   // registers whose dO^T fragment this gap's MFMA has just read
+                tr_read(trf[j], CS, CO + 16 * s2 * ROWB, mt);
+                // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
+                a4_read_k<g_OA(k - 16), NO + QTILE>(a_addr[NS] ^ (uint32_t)((k - 16) << 5));
+            } else if constexpr (k < 28) {          // lse of unit u+1 (this unit's was last read in gap 7)
+                l4[k - 24] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 24)));
+            }
+
+            // ---- P(u): two scores per gap in gaps 0-7, the (rare) mask in gap 8, packed in gaps 8-11
+            if constexpr (k < 8) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * k + e;
+                    pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, -1.4426950408889634f * l4[i >> 2][i & 3]));
+                }
+            }
+            if constexpr (k == 8) {
+                if (need_mask) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
+                        pv[i] = dead ? 0.f : pv[i];
+                        asm volatile("" : "+v"(pv[i]));   // keeps this a branch: as selects it would run for every unit
+                    }
+                }
+            }
+            if constexpr (k >= 8 && k < 12) {
+                constexpr int i = 4 * (k - 8);
+                pf[i >> 3][(i & 7)] = (__bf16)pv[i]; pf[i >> 3][(i & 7) + 1] = (__bf16)pv[i + 1];
+                pf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; pf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
+                if constexpr (k == 9 || k == 11) asm volatile("" : "+v"(pf[(k - 8) >> 1]));   // formed here, not next to its use
+            }
+            // ---- dS(u) = P (dP - delta): two values per gap in gaps 12-19 (dP is complete after gap 7), packed in 20-23
+            if constexpr (k >= 12 && k < 20) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * (k - 12) + e;
+                    pv[i] = pv[i] * (dp[i] - d4[i >> 2][i & 3]);
+                }
+            }
+            if constexpr (k >= 20 && k < 24) {
+                constexpr int i = 4 * (k - 20);
+                dsf[i >> 3][(i & 7)] = (__bf16)pv[i]; dsf[i >> 3][(i & 7) + 1] = (__bf16)pv[i + 1];
+                dsf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; dsf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
+                if constexpr (k == 21 || k == 23) asm volatile("" : "+v"(dsf[(k - 20) >> 1]));
+            }
+            // ---- staging requests of unit u+5 (its slot held unit u-1, which every wave finished before this
+            // iteration's barrier)
+            if constexpr (k == 24) dma_pieces(DMAS);
+            if constexpr (k == 28) dma_consts_and_advance(DMAS);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    if (niter > 0) {
+        // prologue: units 0 .. 4 requested and landed; S(0), then the dO rows and the lse of unit 0
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) { dma_pieces(i); dma_consts_and_advance(i); }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int ks = decltype(I_)::value;
+            a4_read_k<g_QA(ks), 0>(a_addr[0] ^ (uint32_t)(ks << 5));
+            a4_read_k<g_OA(ks), QTILE>(a_addr[0] ^ (uint32_t)(ks << 5));
+        });
+#pragma unroll
+        for (int g = 0; g < 4; ++g) l4[g] = *(LDS_PTR(f32x4, c_ptr[0] + 32 * g));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) {
+            constexpr int ks = decltype(I_)::value;
+            g_mfma_x<g_QA(ks), g_KF(ks), ks == 0, -1>(sv);
+        });
+        a4_nop<12>();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int it = 0;; it += NBUF) {
+            iteration(std::integral_constant<int, 0>{});
+            if (it + 1 >= niter) break;
+            iteration(std::integral_constant<int, 1>{});
+            if (it + 2 >= niter) break;
+            iteration(std::integral_constant<int, 2>{});
+            if (it + 3 >= niter) break;
+            iteration(std::integral_constant<int, 3>{});
+            if (it + 4 >= niter) break;
+            iteration(std::integral_constant<int, 4>{});
+            if (it + 5 >= niter) break;
+            iteration(std::integral_constant<int, 5>{});
+            if (it + 6 >= niter) break;
+        }
+    }
+    // no staging request may outlive the workgroup: its LDS could already belong to another one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: dK^T / dV^T out of the accumulator half (12 wait states after the last MFMA; key on the lane) ->
+    // rows of dk / dv
+    a4_nop<12>();
+    float dvv[MT][16], dkk[MT][16];
+    g_get<0, 64>(&dvv[0][0]);
+    g_get<64, 64>(&dkk[0][0]);
+    if (kj < k_rows) {
+        const int64_t grow = k_row0 + kj;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dcol = 32 * mt + 8 * g4 + 4 * h;
+                if constexpr (ACCUM_F32) {
+                    float* dkp = reinterpret_cast<float*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
+                    float* dvp = reinterpret_cast<float*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
+                    f32x4 a = *reinterpret_cast<f32x4*>(dkp), b = *reinterpret_cast<f32x4*>(dvp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] += dkk[mt][4 * g4 + e] * p.scale; b[e] += dvv[mt][4 * g4 + e]; }
+                    *reinterpret_cast<f32x4*>(dkp) = a;
+                    *reinterpret_cast<f32x4*>(dvp) = b;
+                } else {
+                    __bf16* dkp = reinterpret_cast<__bf16*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
+                    __bf16* dvp = reinterpret_cast<__bf16*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
+                    bf16x4 a, b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = (__bf16)(dkk[mt][4 * g4 + e] * p.scale); b[e] = (__bf16)dvv[mt][4 * g4 + e]; }
+                    *reinterpret_cast<bf16x4*>(dkp) = a;
+                    *reinterpret_cast<bf16x4*>(dvp) = b;
+                }
+            }
+    }
+    asm volatile("" :: "a"(hold[0]), "a"(hold[1]), "a"(hold[2]), "a"(hold[3]), "a"(hold[4]), "a"(hold[5]), "a"(hold[6]), "a"(hold[7]),
+                       "a"(hold[8]), "a"(hold[9]), "a"(hold[10]), "a"(hold[11]), "a"(hold[12]), "a"(hold[13]), "a"(hold[14]), "a"(hold[15]));
+}
+
+int lv_launch_bwd_dkdv_g(const BwdParams& p, int causal, int accum, hipStream_t stream) {
+    if (p.n_blocks <= 0) return 0;
+    dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8)), block(256);
+    const size_t lds = (size_t)6 * (2 * 32 * 128 * 2 + 256);
+    if (causal) {
+        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_g_kernel<true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_bwd_dkdv_g_kernel<true, false>), grid, block, lds, stream, p);
+    } else {
+        if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_g_kernel<false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((lv_bwd_dkdv_g_kernel<false, false>), grid, block, lds, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

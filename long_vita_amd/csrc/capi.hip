@@ -52,8 +52,9 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
     }
     if (dkdv && dkdv[0] && strcmp(dkdv, "default") && strcmp(dkdv, "rs")) {
         if (!strcmp(dkdv, "single")) b = 1;
+        else if (!strcmp(dkdv, "g")) b = 2;
         else if (!strcmp(dkdv, "rs1")) units = 1;
-        else return fail(LV_EINVAL, "unknown dK/dV kernel '%s' (default, rs, rs1, single)", dkdv);
+        else return fail(LV_EINVAL, "unknown dK/dV kernel '%s' (default, rs, rs1, single, g)", dkdv);
     }
     lv_select_bwd_kernels(a, b);
     lv_select_rs_units(units);

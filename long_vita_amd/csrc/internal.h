@@ -91,8 +91,9 @@ struct BwdParams {
 };
 int lv_launch_bwd(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);
 int lv_launch_bwd_dkdv_rs(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);  // role-split dK/dV kernel
+int lv_launch_bwd_dkdv_g(const BwdParams& p, int causal, int accum, hipStream_t stream);          // one wave per SIMD, gap-scheduled dK/dV kernel, d = 128
 int lv_launch_bwd_dq_pp(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);  // ping-pong dQ kernel
-void lv_select_bwd_kernels(int dq, int dkdv);   // 0 default, 1 the earlier kernel, < 0 unchanged
+void lv_select_bwd_kernels(int dq, int dkdv);   // 0 default, 1 the earlier kernel, (dkdv) 2 the gap-scheduled kernel, < 0 unchanged
 void lv_select_rs_units(int n);                  // 32-row units per iteration of the role-split dK/dV kernel: 1 or 2
 int lv_launch_bwd_delta(const void* o, const void* dout, float* delta, int rows, int hq, int d, int64_t o_rs, int64_t o_hs,
                         int64_t do_rs, int64_t do_hs, int64_t lse_stride, hipStream_t stream);

@@ -269,7 +269,7 @@ def test_forward_extreme_score_ranges(forced_forward_kernel):
             assert (err <= lse_bound(ref_lse)).all(), (D, causal, err.max())   # fp32 log-sum-exp of scores in the thousands
 
 
-@pytest.mark.parametrize("dq_kernel,dkdv_kernel", [("default", "default"), ("lockstep", "single"), ("pp", "rs1")])
+@pytest.mark.parametrize("dq_kernel,dkdv_kernel", [("default", "default"), ("lockstep", "single"), ("pp", "rs1"), ("pp", "g")])
 def test_backward_hard_score_ranges(dq_kernel, dkdv_kernel):
     """The backward kernels recompute P from the saved log-sum-exp: scores that climb along the keys with a spike (rows
     dominated by one late key), moderately large scores (sharp but not one-hot rows) and all-zero queries (uniform rows),
@@ -478,7 +478,7 @@ def test_full_size_backward_invariants_cfg3():
     assert (qdq - kdk).abs().max().item() <= 2e-2 * max(qdq.abs().max().item(), kdk.abs().max().item())
 
 
-@pytest.mark.parametrize("dq,dkdv", [("lockstep", "single"), ("pp", "rs1"), ("pp", "rs")])
+@pytest.mark.parametrize("dq,dkdv", [("lockstep", "single"), ("pp", "rs1"), ("pp", "rs"), ("pp", "g")])
 def test_every_backward_kernel_variant(dq, dkdv):
     """The backward kernels that are not the default stay selectable and correct."""
     from long_vita_amd import ops, _lib
