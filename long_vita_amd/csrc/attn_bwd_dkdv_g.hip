@@ -49,6 +49,14 @@ __device__ constexpr int g_VF(int ks) { return 160 + 4 * ks; }
 __device__ constexpr int g_QA(int ks) { return 192 + 4 * ks; }
 __device__ constexpr int g_OA(int ks) { return 224 + 4 * ks; }
 
+// LDS reads that may still be in flight when the MFMA of gap 8 + j takes Q-row fragment j (read in gap 4 + j / 2, two per
+// gap): the fragments read after it in gaps up to 7, and one delta read in each of the gaps 8 .. 7 + j (at most 4); less a
+// margin of one for the order inside a gap, which is the compiler's
+__device__ constexpr int g_qa_wait(int j) {
+    int n = (7 - j) + (j < 4 ? j : 4) - 1;
+    return n < 0 ? 0 : n;
+}
+
 // x (vector registers) = or += A fragment x B fragment, both in the accumulator half; WAIT >= 0: first let all but WAIT
 // LDS reads land
 template <int A, int B, bool FIRST, int WAIT>
@@ -62,15 +70,14 @@ __device__ __forceinline__ void g_mfma_x(f32x16& x) {
 
 // Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i or + 4 i; lds_dst in M0).  As asm so that the compiler
 // does not count them; completion is waited for by hand.
+// M0 is not restored: nothing else in this kernel uses it.
 __device__ __forceinline__ void g_dma16(a4_u32x4 rs, int voff, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 :: "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void g_dma4(const float* g, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                 :: "v"(g), "s"(lds_dst) : "memory");
 }
 
 template <int A, int N>
@@ -233,10 +240,6 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 
     int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
 
-    // LDS reads issued after the read of Q-row fragment j (gap j / 2) and before the MFMA of gap 8 + j that needs it: the
-    // fragments after it (7 - j), the four delta reads of gaps 4-7, two transposed reads in each of the gaps 8 .. 7 + j;
-    // the wait leaves a margin of three for the order inside a gap, which is the compiler's
-    // (gap 8 + j: at most 8 + j reads may still be in flight).
     // One iteration.  SLOT = u mod 6 fixes every ring slot at compile time.
     auto iteration = [&](auto SLOT_) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(SLOT_)::value;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(3 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 
-        bf16x8 trf[2 * MT];       // transposed fragments: dO^T (s2, mt) of this unit in gaps 8-23, then Q^T in gaps 16-31
+        bf16x8 doT[2 * MT], qT[2 * MT];   // transposed fragments (s2, mt) of this unit, each alive for about four gaps
         f32x4 d4[4];              // delta of this unit
         f32x16 dp;
         float pv[16];
@@ -275,31 +278,37 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             if constexpr (k < 8) {
                 g_mfma_x<g_OA(k), g_VF(k), k == 0, -1>(dp);
             } else if constexpr (k < 16) {
-                g_mfma_x<g_QA(k - 8), g_KF(k - 8), k == 8, k>(sv);
+                g_mfma_x<g_QA(k - 8), g_KF(k - 8), k == 8, g_qa_wait(k - 8)>(sv);
             } else if constexpr (k < 24) {
                 constexpr int j = k - 16, s2 = j / MT, mt = j % MT;
-                a4_mfma_o<g_DV(mt), -1>(trf[j], pf[s2]);
+                a4_mfma_o<g_DV(mt), -1>(doT[j], pf[s2]);
             } else {
                 constexpr int j = k - 24, s2 = j / MT, mt = j % MT;
-                a4_mfma_o<g_DK(mt), -1>(trf[j], dsf[s2]);
+                a4_mfma_o<g_DK(mt), -1>(qT[j], dsf[s2]);
             }
             __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its gap's fillers behind it
 
-            // ---- LDS reads
-            if constexpr (k < 4) {                  // Q rows of unit u+1 -> a[192:223], two fragments per gap
-                a4_read_k<g_QA(2 * k), NO>(a_addr[NS] ^ (uint32_t)((2 * k) << 5));
-                a4_read_k<g_QA(2 * k + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * k + 1) << 5));
-            } else if constexpr (k < 8) {           // delta of unit u
-                d4[k - 4] = *(LDS_PTR(f32x4, c_ptr[CS] + CO + 128 + 32 * (k - 4)));
-            } else if constexpr (k < 16) {          // dO^T of unit u, fragment k - 8, needed in gap 16 + (k - 8)
-                constexpr int j = k - 8, s2 = j / MT, mt = j % MT;
-                tr_read(trf[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
-            } else if constexpr (k < 24) {          // Q^T of unit u, fragment k - 16, needed in gap 24 + (k - 16): into the
-                constexpr int j = k - 16, s2 = j / MT, mt = j % MT;   // registers whose dO^T fragment this gap's MFMA has just read
-                tr_read(trf[j], CS, CO + 16 * s2 * ROWB, mt);
-                // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
+            // ---- LDS reads, each about four gaps (128 cycles) ahead of its use: the LDS counter holds 15 requests, and a
+            // wave that has more in flight stalls at the next one
+            if constexpr (k >= 4 && k < 8) {        // Q rows of unit u+1 -> a[192:223], two fragments per gap, for gaps 8-15
+                a4_read_k<g_QA(2 * (k - 4)), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4)) << 5));
+                a4_read_k<g_QA(2 * (k - 4) + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4) + 1) << 5));
+            }
+            if constexpr (k >= 8 && k < 12) {       // delta of unit u, for gaps 12-19
+                d4[k - 8] = *(LDS_PTR(f32x4, c_ptr[CS] + CO + 128 + 32 * (k - 8)));
+            }
+            if constexpr (k >= 12 && k < 20) {      // dO^T of unit u, fragment k - 12, needed in gap 16 + (k - 12)
+                constexpr int j = k - 12, s2 = j / MT, mt = j % MT;
+                tr_read(doT[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
+            }
+            if constexpr (k >= 20 && k < 28) {      // Q^T of unit u, fragment k - 20, needed in gap 24 + (k - 20)
+                constexpr int j = k - 20, s2 = j / MT, mt = j % MT;
+                tr_read(qT[j], CS, CO + 16 * s2 * ROWB, mt);
+            }
+            if constexpr (k >= 16 && k < 24) {      // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
                 a4_read_k<g_OA(k - 16), NO + QTILE>(a_addr[NS] ^ (uint32_t)((k - 16) << 5));
-            } else if constexpr (k < 28) {          // lse of unit u+1 (this unit's was last read in gap 7)
+            }
+            if constexpr (k >= 24 && k < 28) {      // lse of unit u+1 (this unit's was last read in gap 7)
                 l4[k - 24] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 24)));
             }
 
