@@ -21,11 +21,14 @@
  *   [3] k_len    number of key rows from k_row0 the block may attend to
  *   [4] shift    causal rule: key k_row0+j visible to query q_row0+i iff j <= i + shift
  *                (ignored by the non-causal kernels)
- *   [5..7] reserved, must be 0
+ *   [5] out_delta  results (out / lse rows; dq rows) go to row q_row0 + out_delta + i instead of q_row0 + i: 0 for the
+ *                builders above the "split sweeps" section, a workspace row offset for the split tables
+ *   [6..7] reserved, must be 0
  * The backward kernels use the transposed descriptor (one per key block):
  *   [0] k_row0  [1] k_rows (1 .. LV_BWD_BLOCK_N)  [2] q_row0  [3] q_len
  *   [4] shift   key k_row0+j visible to query q_row0+i iff j <= i + shift (q_row0 is the first
  *               32-aligned query row that sees any key of the block)
+ *   [5] out_delta  dk / dv rows go to row k_row0 + out_delta + j
  */
 #ifndef LVATTN_H
 #define LVATTN_H
@@ -141,6 +144,37 @@ int lvattn_select_fwd_kernel(const char* name);
 /* The same for the backward: dq in {"default", "pp", "lockstep"}, dkdv in {"default", "rs" (role-split, two units per
  * iteration), "rs1" (one unit), "single"} -- LVATTN_DQ_KERNEL / LVATTN_DKDV_KERNEL / LVATTN_DKDV_UNITS otherwise. */
 int lvattn_select_bwd_kernels(const char* dq, const char* dkdv);
+
+/* ---- split sweeps: filling the chip at small head counts --------------------------
+ * The reference runs tensor parallel 8 (scripts/modellink/qwen25/finetune_qwen25_14b_intern_300m_ptd_tp8pp1_stage1.sh:101):
+ * each device sees 5 query heads and 1 KV head at the TND call (lcvlm_modellink/core/transformer/dot_product_attention.py:
+ * 352-365).  A packed batch of a few thousand tokens is then a few dozen work items (one 256-row query block, or one
+ * 128-key block, of one head) on 256 compute units.  These entry points cut the sweeps into pieces: every (block, piece)
+ * pair is a work item of its own whose result goes to workspace rows of its own (descriptor word 5, "out_delta": results
+ * are written to row a_row0 + out_delta + i), and a combine kernel merges a block's pieces in a fixed order (bitwise
+ * reproducible, no atomics).  No counterpart in the reference: the NPU op schedules its own cores.
+ *   lv_plan_fwd_split / lv_plan_bwd_split   host, pure CPU: the piece length (keys per piece for the forward and dQ, query rows
+ *       per piece for dK/dV) a simulated heaviest-first schedule on n_cu compute units likes best, or 0 when the launch has
+ *       enough work items (2 x n_cu) or splitting would gain under a tenth.
+ *   lv_build_fwd_blocks_split / lv_build_bwd_blocks_split   host: the descriptor table (heaviest first; returns the count;
+ *       desc_host == NULL only counts) and the combine table comb_host [n_comb][4] = (out_row0, rows, ws_row0, n_pieces): piece p
+ *       of the block is at workspace rows ws_row0 + p * B .. (B = 256 forward / dQ, 128 dK/dV); *ws_rows = workspace rows needed.
+ *       Every block goes through the workspace, also those with one piece.
+ *   lvattn_combine_lse   out / lse <- log-sum-exp merge of the pieces' (out bf16 [ws_rows, hq, d] contiguous, lse [hq, ws_lse_stride])
+ *       written by lvattn_fwd with the split table (pass the workspace as its out / lse).
+ *   lvattn_combine_sum   out (bf16) <- sum of the pieces' fp32 partials ws [ws_rows, heads, d] contiguous, written by lvattn_bwd
+ *       with accum_f32 = 1 into a ZEROED workspace (dq with the forward's split table, dk / dv with the backward's). */
+int lv_plan_fwd_split(const int32_t* cu_seqlens_host, int n_seg, int causal, int heads, int n_cu);
+int lv_plan_bwd_split(const int32_t* cu_seqlens_host, int n_seg, int causal, int kv_heads, int group, int n_cu);
+int lv_build_fwd_blocks_split(const int32_t* cu_seqlens_host, int n_seg, int causal, int piece_keys, int32_t* desc_host, int max_blocks,
+                              int32_t* comb_host, int max_comb, int* n_comb, int* ws_rows);
+int lv_build_bwd_blocks_split(const int32_t* cu_seqlens_host, int n_seg, int causal, int piece_rows, int32_t* desc_host, int max_blocks,
+                              int32_t* comb_host, int max_comb, int* n_comb, int* ws_rows);
+int lvattn_combine_lse(const void* ws_out, const float* ws_lse, void* out, float* lse, const int32_t* comb_dev, int n_comb,
+                       int hq, int d, int64_t ws_lse_stride, int64_t o_row_stride, int64_t o_head_stride, int64_t lse_stride,
+                       void* stream);
+int lvattn_combine_sum(const float* ws, void* out, const int32_t* comb_dev, int n_comb, int block_rows, int heads, int d,
+                       int64_t o_row_stride, int64_t o_head_stride, void* stream);
 
 /* ---- incremental attention over a KV cache -------------------------------------
  * Replaces torch_npu.npu_incre_flash_attention as called with --use-kv-cache

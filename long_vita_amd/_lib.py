@@ -40,6 +40,12 @@ _SIGNATURES = {
     "lvattn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _int, _int, _int, _int, _int,
                           _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                           _f, _int, _int, _vp]),
+    "lv_plan_fwd_split": (_int, [_i32p, _int, _int, _int, _int]),
+    "lv_plan_bwd_split": (_int, [_i32p, _int, _int, _int, _int, _int]),
+    "lv_build_fwd_blocks_split": (_int, [_i32p, _int, _int, _int, _i32p, _int, _i32p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lv_build_bwd_blocks_split": (_int, [_i32p, _int, _int, _int, _i32p, _int, _i32p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lvattn_combine_lse": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _i64, _i64, _i64, _i64, _vp]),
+    "lvattn_combine_sum": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _vp]),
     "lvattn_cast_f32_bf16": (_int, [_vp, _vp, _int, _int, _int, _i64, _i64, _vp]),
     "lvattn_merge": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _i64, _vp]),
     "lvattn_merge_init": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _i64, _i64, _i64, _vp]),

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
 
     // ---- epilogue: dK^T / dV^T accumulators (key on the lane) -> rows of dk / dv
     if (kj < k_rows) {
-        const int64_t grow = k_row0 + kj;
+        const int64_t grow = k_row0 + dsc.out_delta + kj;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void lv_bwd_dq_kernel(BwdParams p) {
 
     // ---- epilogue: dQ^T accumulators (query on the lane) -> rows of dq
     if (qi < q_rows) {
-        const int64_t grow = q_row0 + qi;
+        const int64_t grow = q_row0 + dsc.out_delta + qi;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     g_get<0, 64>(&dvv[0][0]);
     g_get<64, 64>(&dkk[0][0]);
     if (kj < k_rows) {
-        const int64_t grow = k_row0 + kj;
+        const int64_t grow = k_row0 + dsc.out_delta + kj;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 
     // ---- epilogue: accumulators (key on the lane) -> rows of dv (V-wave) or dk (K-wave, times scale)
     if (kj < k_rows) {
-        const int64_t grow = k_row0 + kj;
+        const int64_t grow = k_row0 + dsc.out_delta + kj;
         const float f = is_k ? p.scale : 1.f;
         void* const gbase = is_k ? p.dk : p.dv;
         const int64_t g_rs = is_k ? p.dk_rs : p.dv_rs, g_hs = is_k ? p.dk_hs : p.dv_hs;

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 
     // ---- epilogue: dQ^T accumulators (query on the lane) -> rows of dq
     if (qi < q_rows) {
-        const int64_t grow = q_row0 + qi;
+        const int64_t grow = q_row0 + dsc.out_delta + qi;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
     const bool live = (qi < q_rows);
     const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
     if (live) {
-        __bf16* optr = p.o + (int64_t)(q_row0 + qi) * p.o_rs + (int64_t)head * p.o_hs;
+        __bf16* optr = p.o + (int64_t)(q_row0 + dsc.out_delta + qi) * p.o_rs + (int64_t)head * p.o_hs;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lv_fwd_kernel(FwdParams p) {
             }
         if (h == 0) {
             float lse = (l_tot > 0.f) ? (m_run * p.scale + __logf(l_tot)) : -INFINITY;
-            p.lse[(int64_t)head * p.lse_stride + q_row0 + qi] = lse;
+            p.lse[(int64_t)head * p.lse_stride + q_row0 + dsc.out_delta + qi] = lse;
         }
     }
 }

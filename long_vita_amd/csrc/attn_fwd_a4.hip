@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
     const int q_row0 = __builtin_amdgcn_readfirstlane(dsc.a_row0), q_rows = __builtin_amdgcn_readfirstlane(dsc.a_rows);
     const int k_row0 = __builtin_amdgcn_readfirstlane(dsc.b_row0), k_len = __builtin_amdgcn_readfirstlane(dsc.b_len);
     const int shift = CAUSAL ? __builtin_amdgcn_readfirstlane(dsc.shift) : 0x3fffffff;
+    const int o_row0 = q_row0 + __builtin_amdgcn_readfirstlane(dsc.out_delta);   // where the results go (workspace rows for split sweeps)
 
     // ---- Q fragments of the two column blocks into a[128:191]: lane holds Q[row][16ks + 8h .. +8]
     // row of column block c inside the work item, and the last key it sees (recomputed where needed: registers are short)
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
 #undef A4_G16
 #undef A4_G4
         if (live) {
-            __bf16* optr = p.o + (int64_t)(q_row0 + qi_c) * p.o_rs + (int64_t)head * p.o_hs;
+            __bf16* optr = p.o + (int64_t)(o_row0 + qi_c) * p.o_rs + (int64_t)head * p.o_hs;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void lv_fwd_a4_kernel(FwdParams p) {
                 }
             if (h_e == 0) {
                 float lse = (l_tot > 0.f) ? (m_run[c] * 0.6931471805599453f + __logf(l_tot)) : -INFINITY;
-                p.lse[(int64_t)head * p.lse_stride + q_row0 + qi_c] = lse;
+                p.lse[(int64_t)head * p.lse_stride + o_row0 + qi_c] = lse;
             }
         }
     }

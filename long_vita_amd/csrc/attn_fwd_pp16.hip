@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp16_kernel(FwdParams p) {
         const float l_tot = quad_sum(l_run[qb]);
         const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
         if (qi[qb] < q_rows) {
-            __bf16* optr = p.o + (int64_t)(q_row0 + qi[qb]) * p.o_rs + (int64_t)head * p.o_hs + 4 * g;
+            __bf16* optr = p.o + (int64_t)(q_row0 + dsc.out_delta + qi[qb]) * p.o_rs + (int64_t)head * p.o_hs + 4 * g;
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
                 bf16x4 ov;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp16_kernel(FwdParams p) {
             }
             if (g == 0) {
                 const float lse = (l_tot > 0.f) ? (m_run[qb] * p.scale + __logf(l_tot)) : -INFINITY;
-                p.lse[(int64_t)head * p.lse_stride + q_row0 + qi[qb]] = lse;
+                p.lse[(int64_t)head * p.lse_stride + q_row0 + dsc.out_delta + qi[qb]] = lse;
             }
         }
     }

@@ -81,5 +81,7 @@ struct AttnDesc {
     int b_row0;  // fwd: k_row0   bwd: q_row0
     int b_len;   // fwd: k_len    bwd: q_len
     int shift;
-    int pad0, pad1, pad2;
+    int out_delta;  // results go to row (a_row0 + out_delta + i) of the output tensors instead of row (a_row0 + i): work
+                    // items that split one block's sweep write their partial results to workspace rows of their own
+    int pad1, pad2;
 };

@@ -347,13 +347,138 @@ def attn_fwd_rect_split_keys(q, k, v, scale: float, causal: bool, shift: int = 0
 
 
 # ---------------------------------------------------------------------------
+# split sweeps: filling the chip when a launch has fewer work items than compute units
+# ---------------------------------------------------------------------------
+class SplitTables:
+    """Device tables of one split launch: ``desc`` (work items, one per (block, piece)), ``comb`` (combine entries),
+    ``ws_rows`` workspace rows, ``block_rows`` (256 forward / dQ, 128 dK/dV), ``piece`` the piece length used."""
+
+    def __init__(self, desc, comb, ws_rows, block_rows, piece):
+        self.desc, self.comb, self.ws_rows, self.block_rows, self.piece = desc, comb, ws_rows, block_rows, piece
+
+
+_split_override = {"fwd": None, "bwd": None}     # tests: force a piece length (0 = never split, None = the planner's choice)
+
+
+def set_split_override(fwd=None, bwd=None):
+    """Test hook: force the piece length of the forward / dQ sweeps (keys) and of the dK/dV sweeps (query rows);
+    0 disables splitting, None gives the choice back to the planner."""
+    _split_override["fwd"], _split_override["bwd"] = fwd, bwd
+
+
+def _n_cu(device) -> int:
+    return torch.cuda.get_device_properties(device).multi_processor_count
+
+
+def plan_split(cu_seqlens, causal: bool, hq: int, hkv: int, device):
+    """(piece_keys, piece_rows) for the forward / dQ and the dK/dV launch of a packed batch: 0 = leave that launch as it
+    is.  The planner simulates a heaviest-first schedule of the launch's work items on the device's compute units and
+    cuts the sweeps when the launch has too few items to fill them (lv_plan_fwd_split / lv_plan_bwd_split)."""
+    cu = np.ascontiguousarray(np.asarray(cu_seqlens, dtype=np.int32))
+    n_seg = cu.shape[0] - 1
+    L = _lib.lib()
+    n_cu = _n_cu(device)
+    pf = _split_override["fwd"]
+    pb = _split_override["bwd"]
+    if pf is None:
+        pf = check(L.lv_plan_fwd_split(cu.ctypes.data_as(_I32P), n_seg, int(causal), hq, n_cu), "lv_plan_fwd_split")
+    if pb is None:
+        pb = check(L.lv_plan_bwd_split(cu.ctypes.data_as(_I32P), n_seg, int(causal), hkv, hq // hkv, n_cu), "lv_plan_bwd_split")
+    return int(pf), int(pb)
+
+
+def split_tables_on_device(cu_seqlens, causal: bool, backward: bool, piece: int, device) -> SplitTables:
+    """Split tables of a packed batch (cached like the plain descriptor tables).  ``piece`` = keys per piece (forward /
+    dQ) or query rows per piece (dK/dV); a huge value gives one piece per block (the launch then merely goes through
+    the workspace)."""
+    key = ("split", tuple(int(x) for x in cu_seqlens), bool(causal), bool(backward), int(piece), str(device))
+
+    def build():
+        import ctypes
+        cu = np.ascontiguousarray(np.asarray(cu_seqlens, dtype=np.int32))
+        n_seg = cu.shape[0] - 1
+        fn = _lib.lib().lv_build_bwd_blocks_split if backward else _lib.lib().lv_build_fwd_blocks_split
+        n_comb, ws_rows = ctypes.c_int(0), ctypes.c_int(0)
+        n = check(fn(cu.ctypes.data_as(_I32P), n_seg, int(causal), int(piece), None, 0, None, 0, ctypes.byref(n_comb), ctypes.byref(ws_rows)),
+                  "lv_build_blocks_split")
+        desc = np.zeros((max(n, 1), LV_DESC_INTS), dtype=np.int32)
+        comb = np.zeros((max(n_comb.value, 1), 4), dtype=np.int32)
+        n = check(fn(cu.ctypes.data_as(_I32P), n_seg, int(causal), int(piece), desc.ctypes.data_as(_I32P), desc.shape[0],
+                     comb.ctypes.data_as(_I32P), comb.shape[0], ctypes.byref(n_comb), ctypes.byref(ws_rows)), "lv_build_blocks_split")
+        return SplitTables(_to_device(desc[:n], device), torch.from_numpy(comb[:n_comb.value]).to(device), int(ws_rows.value),
+                           LV_BWD_BLOCK_N if backward else 256, int(piece))
+    return _blocks.get(key, build)
+
+
+_ONE_PIECE = 1 << 30     # a "piece length" that leaves every sweep whole
+
+
+def combine_lse_launch(ws_out, ws_lse, out, lse, tables: SplitTables):
+    hq, d = out.shape[1], out.shape[2]
+    check(_lib.lib().lvattn_combine_lse(_ptr(ws_out), _ptr(ws_lse), _ptr(out), _ptr(lse), _ptr(tables.comb), tables.comb.shape[0],
+                                        hq, d, ws_lse.stride(0), out.stride(0), out.stride(1), lse.stride(0), _stream()),
+          "lvattn_combine_lse")
+
+
+def combine_sum_launch(ws, out, tables: SplitTables):
+    heads, d = out.shape[1], out.shape[2]
+    check(_lib.lib().lvattn_combine_sum(_ptr(ws), _ptr(out), _ptr(tables.comb), tables.comb.shape[0], tables.block_rows, heads, d,
+                                        out.stride(0), out.stride(1), _stream()), "lvattn_combine_sum")
+
+
+def attn_fwd_split_launch(q, k, v, tables: SplitTables, scale: float, causal: bool, covered: bool = False):
+    """Forward of a packed batch through split tables: one launch over every (block, piece) pair into a workspace, then
+    the log-sum-exp combine.  Rows no segment covers come back as zeros / -inf (``covered``: there are none)."""
+    rq, hq, d = q.shape
+    dev = q.device
+    ws_out = torch.empty((tables.ws_rows, hq, d), dtype=torch.bfloat16, device=dev)
+    ws_lse = torch.empty((hq, tables.ws_rows), dtype=torch.float32, device=dev)
+    attn_fwd_launch(q, k, v, tables.desc, scale, causal, ws_out, ws_lse)
+    if covered:
+        out = torch.empty((rq, hq, d), dtype=torch.bfloat16, device=dev)
+        lse = torch.empty((hq, rq), dtype=torch.float32, device=dev)
+    else:
+        out = torch.zeros((rq, hq, d), dtype=torch.bfloat16, device=dev)
+        lse = torch.full((hq, rq), float("-inf"), dtype=torch.float32, device=dev)
+    combine_lse_launch(ws_out, ws_lse, out, lse, tables)
+    return out, lse
+
+
+def attn_bwd_split_launch(q, k, v, out, dout, lse, tq: SplitTables, tk: SplitTables, scale: float, causal: bool,
+                          covered: bool = False):
+    """Backward through split tables: fp32 partials of dq (forward-form table) and dk / dv (key-block table) in zeroed
+    workspaces, summed per block in a fixed order.  Returns bf16 (dq, dk, dv)."""
+    rq, hq, d = q.shape
+    rk, hkv, _ = k.shape
+    dev = q.device
+    dq_ws = torch.zeros((tq.ws_rows, hq, d), dtype=torch.float32, device=dev)
+    dk_ws = torch.zeros((tk.ws_rows, hkv, d), dtype=torch.float32, device=dev)
+    dv_ws = torch.zeros((tk.ws_rows, hkv, d), dtype=torch.float32, device=dev)
+    attn_bwd_launch(q, k, v, out, dout, lse, tq.desc, tk.desc, scale, causal, dq_ws, dk_ws, dv_ws, accum_f32=True)
+    make = torch.empty if covered else torch.zeros       # rows no segment covers get a zero gradient
+    dq = make((rq, hq, d), dtype=torch.bfloat16, device=dev)
+    dk = make((rk, hkv, d), dtype=torch.bfloat16, device=dev)
+    dv = make((rk, hkv, d), dtype=torch.bfloat16, device=dev)
+    combine_sum_launch(dq_ws, dq, tq)
+    combine_sum_launch(dk_ws, dk, tk)
+    combine_sum_launch(dv_ws, dv, tk)
+    return dq, dk, dv
+
+
+# ---------------------------------------------------------------------------
 # autograd: packed variable-length attention
 # ---------------------------------------------------------------------------
 class _VarlenAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu_seqlens, scale, causal):
         total = q.shape[0]
-        if len(cu_seqlens) == 2 and cu_seqlens[0] == 0 and cu_seqlens[1] == total == k.shape[0]:
+        # few work items for the chip (small head counts, short batches): cut the sweeps into pieces
+        ctx.pieces = plan_split(cu_seqlens, causal, q.shape[1], k.shape[1], q.device) if q.is_cuda else (0, 0)
+        ctx.covered = len(cu_seqlens) > 1 and cu_seqlens[0] == 0 and cu_seqlens[-1] == total == k.shape[0]
+        if ctx.pieces[0] > 0:
+            out, lse = attn_fwd_split_launch(q, k, v, split_tables_on_device(cu_seqlens, causal, False, ctx.pieces[0], q.device),
+                                             scale, causal, ctx.covered)
+        elif len(cu_seqlens) == 2 and cu_seqlens[0] == 0 and cu_seqlens[1] == total == k.shape[0]:
             out, lse = attn_fwd_dense_launch(q, k, v, scale, causal)      # one segment over every row: no descriptors
         else:
             desc = blocks_on_device(cu_seqlens, causal, False, q.device)
@@ -371,6 +496,12 @@ class _VarlenAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dlse):
         q, k, v, out, lse = ctx.saved_tensors
+        pf, pb = ctx.pieces
+        if pf > 0 or pb > 0:      # one launch takes one kind of output buffer: when either sweep is cut, both go through workspaces
+            tq = split_tables_on_device(ctx.cu_seqlens, ctx.causal, False, pf if pf > 0 else _ONE_PIECE, q.device)
+            tk = split_tables_on_device(ctx.cu_seqlens, ctx.causal, True, pb if pb > 0 else _ONE_PIECE, q.device)
+            dq, dk, dv = attn_bwd_split_launch(q, k, v, out, dout, lse, tq, tk, ctx.scale, ctx.causal, ctx.covered)
+            return dq, dk, dv, None, None, None
         desc_q = blocks_on_device(ctx.cu_seqlens, ctx.causal, False, q.device)
         desc_k = blocks_on_device(ctx.cu_seqlens, ctx.causal, True, q.device)
         dq, dk, dv, _ = attn_bwd_launch(q, k, v, out, dout, lse, desc_q, desc_k, ctx.scale, ctx.causal)

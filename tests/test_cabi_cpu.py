@@ -163,3 +163,79 @@ def test_argument_validation_rejects_before_any_launch():
     # unknown kernel name
     assert L.lvattn_select_fwd_kernel(b"nope") != 0 and "unknown forward kernel" in err()
     assert L.lvattn_select_fwd_kernel(b"default") == 0
+
+
+def _split_tables(fn, cu, causal, piece):
+    import ctypes
+    cu_a = np.asarray(cu, dtype=np.int32)
+    p = cu_a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    n_comb, ws_rows = ctypes.c_int(0), ctypes.c_int(0)
+    n = fn(p, len(cu) - 1, causal, piece, None, 0, None, 0, ctypes.byref(n_comb), ctypes.byref(ws_rows))
+    assert n >= 0
+    desc = np.zeros((max(n, 1), 8), dtype=np.int32)
+    comb = np.zeros((max(n_comb.value, 1), 4), dtype=np.int32)
+    n2 = fn(p, len(cu) - 1, causal, piece, desc.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), desc.shape[0],
+            comb.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), comb.shape[0], ctypes.byref(n_comb), ctypes.byref(ws_rows))
+    assert n2 == n
+    return desc[:n], comb[:n_comb.value], ws_rows.value
+
+
+@pytest.mark.parametrize("cu,causal", [([0, 8192], 1), ([0, 300, 301, 2000, 2000, 5000], 1), ([0, 1000, 3000], 0), ([0, 77], 1)])
+def test_split_tables_cover_every_visible_pair_exactly_once(cu, causal):
+    """The split-sweep tables (host side, no GPU): the pieces of the forward table and of the dK/dV table each cover every
+    (query row, key) pair the packed causal (or full) mask allows exactly once and nothing else; every work item writes
+    to workspace rows of its own; the combine entries list each block's pieces back to back."""
+    from long_vita_amd import _lib
+    L = _lib.lib()
+    T = cu[-1]
+    seg = np.full(T, -1)
+    for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+        seg[a:b] = i
+    want = (seg[:, None] == seg[None, :]) & (seg[:, None] >= 0)
+    if causal:
+        want &= np.arange(T)[None, :] <= np.arange(T)[:, None]
+    for backward, fn, blk, piece in ((False, L.lv_build_fwd_blocks_split, 256, 512), (True, L.lv_build_bwd_blocks_split, 128, 256),
+                                     (False, L.lv_build_fwd_blocks_split, 256, 1 << 30)):
+        desc, comb, ws_rows = _split_tables(fn, cu, causal, piece)
+        cover = np.zeros((T, T), dtype=np.int32)
+        ws_used = np.zeros(ws_rows, dtype=np.int32)
+        for a0, an, b0, bn, sh, od, _, _ in desc:
+            assert 0 < an <= blk and bn >= 0
+            ws_used[a0 + od:a0 + od + an] += 1
+            ai = np.arange(an)[:, None]
+            bj = np.arange(bn)[None, :]
+            if backward:      # a = keys (jj), b = query rows (ii): jj <= ii + shift
+                vis = (ai <= bj + sh) if causal else np.ones((an, bn), bool)
+                cover[b0:b0 + bn, a0:a0 + an] += vis.T
+            else:             # a = query rows (i), b = keys (j): j <= i + shift
+                vis = (bj <= ai + sh) if causal else np.ones((an, bn), bool)
+                cover[a0:a0 + an, b0:b0 + bn] += vis
+        assert (cover == want).all(), (backward, piece)
+        assert ws_used.max() <= 1
+        assert int(comb[:, 3].sum()) == len(desc) and ws_rows == blk * len(desc)
+        rows_covered = np.zeros(T, dtype=np.int32)
+        for out_row0, rows, ws_row0, n_pieces in comb:
+            rows_covered[out_row0:out_row0 + rows] += 1
+            for pc in range(n_pieces):
+                assert (ws_used[ws_row0 + pc * blk: ws_row0 + pc * blk + rows] == 1).all()
+        assert (rows_covered == (seg >= 0)).all()
+        if backward and piece < (1 << 30):
+            assert all(bn % 32 == 0 or b0 + bn == cu[np.searchsorted(cu, b0, side="right")] for _, _, b0, bn, *_ in desc)
+
+
+def test_split_planner_rule():
+    """lv_plan_*_split: enough work items -> 0; one tensor-parallel rank's head count on a short batch -> a piece length."""
+    import ctypes
+    from long_vita_amd import _lib
+    L = _lib.lib()
+
+    def plan(cu, heads_q, heads_kv, n_cu=256):
+        a = np.asarray(cu, dtype=np.int32)
+        p = a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        return (L.lv_plan_fwd_split(p, len(cu) - 1, 1, heads_q, n_cu), L.lv_plan_bwd_split(p, len(cu) - 1, 1, heads_kv, heads_q // heads_kv, n_cu))
+    assert plan([0, 131072], 40, 8) == (0, 0)                  # 20,480 forward items: nothing to gain
+    pf, pb = plan([0, 8192], 5, 1)                             # 160 forward items / 64 key blocks on 256 compute units
+    assert pf >= 256 and pf % 256 == 0 and pb >= 256 and pb % 32 == 0
+    assert plan([0, 8192], 40, 8)[0] == 0 or plan([0, 8192], 40, 8)[0] >= 256
+    assert plan(list(range(0, 4096 + 1, 256)), 5, 1)[0] == 0   # 16 one-block segments: no sweep longer than a piece
+    assert L.lv_plan_fwd_split(None, 1, 1, 5, 256) < 0
