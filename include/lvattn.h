@@ -23,12 +23,16 @@
  *                (ignored by the non-causal kernels)
  *   [5] out_delta  results (out / lse rows; dq rows) go to row q_row0 + out_delta + i instead of q_row0 + i: 0 for the
  *                builders above the "split sweeps" section, a workspace row offset for the split tables
- *   [6..7] reserved, must be 0
+ *   [6] band + 1  0: plain causal rule.  b + 1: key k_row0+j visible to query q_row0+i iff i + shift - b <= j <= i + shift
+ *                (a query sees itself and the b keys before it: pre_tockens / --sliding-window,
+ *                dot_product_attention.py:403-406, 462; written by the *_band builders, read by launches with causal == 2)
+ *   [7] reserved, must be 0
  * The backward kernels use the transposed descriptor (one per key block):
  *   [0] k_row0  [1] k_rows (1 .. LV_BWD_BLOCK_N)  [2] q_row0  [3] q_len
  *   [4] shift   key k_row0+j visible to query q_row0+i iff j <= i + shift (q_row0 is the first
  *               32-aligned query row that sees any key of the block)
  *   [5] out_delta  dk / dv rows go to row k_row0 + out_delta + j
+ *   [6] band + 1   as above
  */
 #ifndef LVATTN_H
 #define LVATTN_H
@@ -73,6 +77,13 @@ int lv_build_fwd_blocks(const int32_t* cu_seqlens_host, int n_seg, int causal,
                         int32_t* desc_host, int max_blocks);
 int lv_build_bwd_blocks(const int32_t* cu_seqlens_host, int n_seg, int causal,
                         int32_t* desc_host, int max_blocks);
+/* Banded causal attention (the fused op's band modes: sparse_mode 0 / 1 / 4 with pre_tockens smaller than a segment,
+ * lcvlm_modellink/core/transformer/dot_product_attention.py:403-406, 454-467; --sliding-window sets pre_tockens): a query
+ * sees itself and the `band` keys before it inside its segment.  The sweep of a work item is trimmed to the band.  Launch
+ * lvattn_fwd / lvattn_bwd on these tables with causal == 2 (the kernels that read the band are then selected). */
+int lv_build_fwd_blocks_band(const int32_t* cu_seqlens_host, int n_seg, int band, int32_t* desc_host, int max_blocks);
+int lv_build_bwd_blocks_band(const int32_t* cu_seqlens_host, int n_seg, int band, int32_t* desc_host, int max_blocks);
+int lv_build_fwd_blocks_rect_band(int q_row0, int q_len, int k_row0, int k_len, int shift, int band, int32_t* desc_host, int max_blocks);
 /* One rectangular (q rows x k rows) region, e.g. a ring step: q_row0..+q_len
  * against k_row0..+k_len, with `shift` as above when causal. */
 int lv_build_fwd_blocks_rect(int q_row0, int q_len, int k_row0, int k_len, int causal, int shift,

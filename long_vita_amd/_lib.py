@@ -40,6 +40,9 @@ _SIGNATURES = {
     "lvattn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _int, _int, _int, _int, _int,
                           _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                           _f, _int, _int, _vp]),
+    "lv_build_fwd_blocks_band": (_int, [_i32p, _int, _int, _i32p, _int]),
+    "lv_build_bwd_blocks_band": (_int, [_i32p, _int, _int, _i32p, _int]),
+    "lv_build_fwd_blocks_rect_band": (_int, [_int, _int, _int, _int, _int, _int, _i32p, _int]),
     "lv_plan_fwd_split": (_int, [_i32p, _int, _int, _int, _int]),
     "lv_plan_bwd_split": (_int, [_i32p, _int, _int, _int, _int, _int]),
     "lv_build_fwd_blocks_split": (_int, [_i32p, _int, _int, _int, _i32p, _int, _i32p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

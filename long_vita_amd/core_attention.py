@@ -116,8 +116,8 @@ def flash_attention_forward(self, query, key, value, attention_mask, attn_mask_t
         if args.shape_order != "SBH":
             raise ValueError("FlashAttention with Alibi requires for SBH shape_order, but is {}.".format(args.shape_order))
         raise NotImplementedError("alibi is not supported")
-    if args.sliding_window is not None and seq_length > args.sliding_window:
-        raise NotImplementedError("sliding-window attention is not supported")
+    # :403-406: a sliding window sets pre_tockens (the reference writes it into the global args; here it stays local)
+    pre_tockens = args.sliding_window if (args.sliding_window is not None and seq_length > args.sliding_window) else args.pre_tockens
     if getattr(args, "use_kv_cache", False):
         # :428-452: 's b h -> b s h' views of the cache, one new token -> incremental op, else the prompt op
         q, k, v = (x.reshape(x.shape[0], x.shape[1], -1).transpose(0, 1) for x in (query, key, value))
@@ -125,9 +125,11 @@ def flash_attention_forward(self, query, key, value, attention_mask, attn_mask_t
             output = npu_incre_flash_attention(q, k, v, num_heads=n_head, input_layout="BSH", pse_shift=None,
                                                padding_mask=None, scale_value=scale)
         else:
+            # the reference forwards args.sparse_mode and args.pre_tockens (:445, :449): in the op's band modes (0 / 1 / 4) a
+            # prompt longer than pre_tockens is attended under that band
             output = npu_prompt_flash_attention(q, k, v, num_heads=n_head, input_layout="BSH", pse_shift=None,
-                                                sparse_mode=2, padding_mask=None, atten_mask=True, scale_value=scale,
-                                                pre_tokens=args.pre_tockens, next_tokens=0)
+                                                sparse_mode=args.sparse_mode, padding_mask=None, atten_mask=True,
+                                                scale_value=scale, pre_tokens=pre_tockens, next_tokens=0)
         return output.transpose(0, 1)
     causal_mask = True  # generic path: the causal template mask (:384) / get_attention_mask()
     if args.shape_order == "TND":
@@ -135,17 +137,20 @@ def flash_attention_forward(self, query, key, value, attention_mask, attn_mask_t
         actual_seq_len = state.get_actual_seq_len()
         to_t = lambda x: x.reshape(x.shape[0] * batch_size, x.shape[2], head_dim)
         out = npu_fusion_attention(to_t(query), to_t(key), to_t(value), n_head, "TND", atten_mask=causal_mask, scale=scale,
-                                   pre_tockens=args.pre_tockens, next_tockens=0, keep_prob=1 - dropout_p, sparse_mode=4,
+                                   pre_tockens=pre_tockens, next_tockens=0, keep_prob=1 - dropout_p, sparse_mode=4,
                                    actual_seq_qlen=actual_seq_len, actual_seq_kvlen=actual_seq_len)[0]
         return out.reshape(seq_length, batch_size, n_head * head_dim)
     if args.shape_order == "BNSD":
         to_b = lambda x: x.permute(1, 2, 0, 3)
         out = npu_fusion_attention(to_b(query), to_b(key), to_b(value), n_head, "BNSD", atten_mask=causal_mask, scale=scale,
-                                   keep_prob=1 - dropout_p, sparse_mode=2)[0]
+                                   pre_tockens=pre_tockens, next_tockens=args.next_tockens, keep_prob=1 - dropout_p,
+                                   sparse_mode=args.sparse_mode)[0]
         return out.permute(2, 0, 1, 3).reshape(seq_length, batch_size, n_head * head_dim)
     q, k, v = (x.reshape(x.shape[0], x.shape[1], -1) for x in (query, key, value))
-    return npu_fusion_attention(q, k, v, n_head, "SBH", atten_mask=causal_mask, scale=scale, keep_prob=1 - dropout_p,
-                                sparse_mode=2)[0]
+    # the reference forwards args.sparse_mode / pre_tockens / next_tockens (:462-466): in the op's band modes (0, the
+    # default, 1 and 4) a sequence longer than pre_tockens (65,536 by default) is attended under that band
+    return npu_fusion_attention(q, k, v, n_head, "SBH", atten_mask=causal_mask, scale=scale, pre_tockens=pre_tockens,
+                                next_tockens=args.next_tockens, keep_prob=1 - dropout_p, sparse_mode=args.sparse_mode)[0]
 
 
 def dot_product_attention_forward_wrapper(fn):

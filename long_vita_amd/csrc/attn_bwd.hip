@@ -649,7 +649,11 @@ void lv_select_bwd_kernels(int dq, int dkdv) {
 template <int D>
 static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     dim3 block(512);
-    if (p.n_blocks > 0 && dkdv_choice() == 2 && D == 128) {
+    const bool banded = (causal == 2);     // descriptors with a band: the role-split dK/dV and the ping-pong dQ kernels read it
+    causal = causal != 0;
+    if (p.n_blocks > 0 && banded) {
+        lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);
+    } else if (p.n_blocks > 0 && dkdv_choice() == 2 && D == 128) {
         lv_launch_bwd_dkdv_g(p, causal, accum, stream);
     } else if (p.n_blocks > 0 && dkdv_choice() != 1) {
         lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);
@@ -665,7 +669,7 @@ static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stre
             else hipLaunchKernelGGL((lv_bwd_dkdv_kernel<D, false, false>), grid, block, lds, stream, p);
         }
     }
-    if (p.n_qblocks > 0 && dq_pingpong()) {
+    if (p.n_qblocks > 0 && (banded || dq_pingpong())) {
         lv_launch_bwd_dq_pp(p, D, causal, accum, stream);
     } else if (p.n_qblocks > 0) {
         dim3 grid((unsigned)((int64_t)p.n_qblocks * p.hq));

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
     const int k_row0 = dsc.a_row0, k_rows = dsc.a_rows;
     const int q_row0 = dsc.b_row0, q_len = dsc.b_len;
     const int shift = CAUSAL ? dsc.shift : 0x3fffffff;
+    const int band_low = CAUSAL ? lv_band_low(dsc) : -(1 << 29);   // key kj visible to row ii only if kj >= ii + band_low
     const int nslice = (q_len + BQ - 1) / BQ;
     const int nunits = nslice * p.group;
     const int niter = (nunits + NSL - 1) / NSL;   // the last iteration may hold dead units (P forced to 0)
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                 ++c_n;
                 if (++c_hg == p.group) { c_hg = 0; --c_sl; }
                 if (!is_k) {
-                    const bool need_mask = dead_unit || (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+                    const bool need_mask = dead_unit || (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows) ||
+                                           (kbase_w < i0 + BQ - 1 + band_low);
                     float pv[16];
 #pragma unroll
 #if LV_RS_CFOLD
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows) | dead_unit;
+                            bool dead = (kj > ii + shift) | (kj < ii + band_low) | (ii >= q_len) | (kj >= k_rows) | dead_unit;
                             pv[i] = dead ? 0.f : pv[i];
                             asm volatile("" : "+v"(pv[i]));  // keeps this a branch
                         }

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 
     int limit = qi + shift;
     if (limit > k_len - 1 || qi >= q_rows) limit = k_len - 1;
+    const int band_low = CAUSAL ? lv_band_low(dsc) : -(1 << 29);   // the band's lower end, when the descriptor has one
+    const int low = qi + band_low;
     int wave_kmax = 32 * w + 32 + shift;
     wave_kmax = wave_kmax < 0 ? 0 : (wave_kmax > k_len ? k_len : wave_kmax);
     const int nkt = (k_len + BN - 1) / BN;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
             // ================= VALU(t): dS_t =================
             if (t < my_nkt) {
                 const int kb0 = t * BN;
-                const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len);
+                const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len) || (kb0 < 32 * w + 31 + band_low);
                 // all the multiply-adds, then all the exponentials, then their consumers: back to back a
                 // dependent pair would stall on the first one's latency sixteen times over
                 float pv[16];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         int j = kb0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        pv[i] = (j > limit) ? 0.f : pv[i];
+                        pv[i] = (j > limit || j < low) ? 0.f : pv[i];
                         asm volatile("" : "+v"(pv[i]));  // keeps this a branch
                     }
                 }

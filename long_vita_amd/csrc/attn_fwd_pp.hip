@@ -149,6 +149,8 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 
     int limit = qi + shift;  // visible keys (relative to k_row0) for this lane's row: j <= limit
     if (limit > k_len - 1 || qi >= q_rows) limit = k_len - 1;
+    const int band_low = CAUSAL ? lv_band_low(dsc) : -(1 << 29);   // ... and j >= qi + band_low when the descriptor has a band
+    const int low = qi + band_low;
     int wave_kmax = 32 * w + 32 + shift;
     wave_kmax = wave_kmax < 0 ? 0 : (wave_kmax > k_len ? k_len : wave_kmax);
     const int nkt = (k_len + BN - 1) / BN;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
             // ================= VALU(t): softmax of S_t -> P_t =================
             if (t < my_nkt) {
                 const int kb0 = t * BN;
-                const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len);
+                const bool need_mask = (kb0 + BN - 1 > 32 * w + shift) || (kb0 + BN > k_len) || (kb0 < 32 * w + 31 + band_low);
                 // Optimistic pass: once every row of the wave has a finite running maximum, P is formed
                 // against it WITHOUT looking for the tile's maximum first (a third of the softmax's
                 // instructions).  Scores far below the running maximum just give tiny P; a score far above
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(512) void lv_fwd_pp_kernel(FwdParams p) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             int j = kb0 + 32 * st + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            s[st][i] = (j > limit) ? -INFINITY : s[st][i];
+                            s[st][i] = (j > limit || j < low) ? -INFINITY : s[st][i];
                         }
                 }
                 float mx = s[0][0];

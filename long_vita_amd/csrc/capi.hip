@@ -109,7 +109,9 @@ int emit(std::vector<HostDesc>& blocks, int32_t* out, int max_blocks) {
 }
 
 // forward: query blocks of a rectangle q[q0, q0+ql) x k[k0, k0+kl)
-void fwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift) {
+// (band >= 0: a row also sees no key more than `band` positions before its last visible one; the sweep of a block then
+// starts at the first 64-key tile its first row needs)
+void fwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift, int band = -1) {
     const int BM = lvattn_fwd_block_m();
     for (int m = 0; m < ql; m += BM) {
         HostDesc d{};
@@ -121,15 +123,20 @@ void fwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int
             int64_t vis = (int64_t)rows + sh;  // keys visible to the last row
             klen = (int)std::max<int64_t>(0, std::min<int64_t>(kl, vis));
         }
-        d.v[0] = q0 + m; d.v[1] = rows; d.v[2] = k0; d.v[3] = klen; d.v[4] = sh;
-        d.work = (int64_t)rows * klen;
+        int kstart = 0;
+        if (causal && band >= 0) {
+            kstart = (int)std::min<int64_t>(std::max<int64_t>(0, (int64_t)sh - band), klen) & ~63;
+            d.v[6] = band + 1;
+        }
+        d.v[0] = q0 + m; d.v[1] = rows; d.v[2] = k0 + kstart; d.v[3] = klen - kstart; d.v[4] = sh - kstart;
+        d.work = (int64_t)rows * (klen - kstart);
         blocks.push_back(d);
     }
 }
 
 // backward: key blocks of the same rectangle; query rows that see at least one key of
 // the block start at i >= j0 - shift.
-void bwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift) {
+void bwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int causal, int shift, int band = -1) {
     for (int n = 0; n < kl; n += LV_BWD_BLOCK_N) {
         HostDesc d{};
         int rows = std::min(LV_BWD_BLOCK_N, kl - n);
@@ -142,8 +149,15 @@ void bwd_rect(std::vector<HostDesc>& blocks, int q0, int ql, int k0, int kl, int
             qstart &= ~31;                 // keep 32-row slices aligned to the block start
             sh = shift + qstart - n;       // jj <= ii + sh with ii relative to qstart
         }
-        d.v[0] = k0 + n; d.v[1] = rows; d.v[2] = q0 + qstart; d.v[3] = ql - qstart; d.v[4] = sh;
-        d.work = (int64_t)rows * (ql - qstart);
+        int qlen = ql - qstart;
+        if (causal && band >= 0) {
+            // query ii (relative to qstart) sees key jj of the block only while jj >= ii + sh - band: the last such row is
+            // ii = rows - 1 - sh + band
+            qlen = (int)std::max<int64_t>(0, std::min<int64_t>(qlen, (int64_t)rows - sh + band));
+            d.v[6] = band + 1;
+        }
+        d.v[0] = k0 + n; d.v[1] = rows; d.v[2] = q0 + qstart; d.v[3] = qlen; d.v[4] = sh;
+        d.work = (int64_t)rows * qlen;
         blocks.push_back(d);
     }
 }
@@ -167,6 +181,26 @@ extern "C" int lv_build_bwd_blocks(const int32_t* cu, int n_seg, int causal, int
     if (int e = check_cu(cu, n_seg)) return e;
     std::vector<HostDesc> blocks;
     for (int i = 0; i < n_seg; ++i) bwd_rect(blocks, cu[i], cu[i + 1] - cu[i], cu[i], cu[i + 1] - cu[i], causal, 0);
+    return emit(blocks, out, max_blocks);
+}
+extern "C" int lv_build_fwd_blocks_band(const int32_t* cu, int n_seg, int band, int32_t* out, int max_blocks) {
+    if (int e = check_cu(cu, n_seg)) return e;
+    if (band < 0) return fail(LV_EINVAL, "band %d < 0", band);
+    std::vector<HostDesc> blocks;
+    for (int i = 0; i < n_seg; ++i) fwd_rect(blocks, cu[i], cu[i + 1] - cu[i], cu[i], cu[i + 1] - cu[i], 1, 0, band);
+    return emit(blocks, out, max_blocks);
+}
+extern "C" int lv_build_bwd_blocks_band(const int32_t* cu, int n_seg, int band, int32_t* out, int max_blocks) {
+    if (int e = check_cu(cu, n_seg)) return e;
+    if (band < 0) return fail(LV_EINVAL, "band %d < 0", band);
+    std::vector<HostDesc> blocks;
+    for (int i = 0; i < n_seg; ++i) bwd_rect(blocks, cu[i], cu[i + 1] - cu[i], cu[i], cu[i + 1] - cu[i], 1, 0, band);
+    return emit(blocks, out, max_blocks);
+}
+extern "C" int lv_build_fwd_blocks_rect_band(int q0, int ql, int k0, int kl, int shift, int band, int32_t* out, int max_blocks) {
+    if (q0 < 0 || ql < 0 || k0 < 0 || kl < 0 || band < 0) return fail(LV_EINVAL, "negative rectangle or band");
+    std::vector<HostDesc> blocks;
+    fwd_rect(blocks, q0, ql, k0, kl, 1, shift, band);
     return emit(blocks, out, max_blocks);
 }
 extern "C" int lv_build_fwd_blocks_rect(int q0, int ql, int k0, int kl, int causal, int shift, int32_t* out, int max_blocks) {
@@ -262,7 +296,12 @@ static int fwd_impl(const void* q, const void* k, const void* v, void* out, floa
         p.rope_cos = (const __bf16*)rope->cos_tab; p.rope_sin = (const __bf16*)rope->sin_tab; p.rope_pos = rope->pos_ids;
         p.rope_tab_rows = rope->tab_rows; p.rope_tab_div = rope->tab_div;
         p.q_rot = (__bf16*)rope->q_rot; p.qr_rs = rope->qr_rs; p.qr_hs = rope->qr_hs;
-        if (lv_launch_fwd_pp(p, d, causal, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+        if (lv_launch_fwd_pp(p, d, causal != 0, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return LV_OK;
+    }
+    if (causal == 2) {     // descriptors with a band: the ping-pong kernel is the one that reads it
+        if (dense || fwd_waves() != 8) return fail(LV_EINVAL, "banded launch: needs descriptors of 256-row work items");
+        if (lv_launch_fwd_pp(p, d, 1, (hipStream_t)stream)) return fail(LV_ELAUNCH, "forward launch failed: %s", hipGetErrorString(hipGetLastError()));
         return LV_OK;
     }
     const int rc = fwd_a4(d, k_rs, v_rs, q_rows_total, k_rows_total, causal, mean_keys) ? lv_launch_fwd_a4(p, causal, (hipStream_t)stream)

@@ -83,5 +83,11 @@ struct AttnDesc {
     int shift;
     int out_delta;  // results go to row (a_row0 + out_delta + i) of the output tensors instead of row (a_row0 + i): work
                     // items that split one block's sweep write their partial results to workspace rows of their own
-    int pad1, pad2;
+    int band_p1;    // 0: plain causal rule.  b + 1: a band as well, key j visible to row i iff i + shift - b <= j <= i + shift
+                    // (taken by the ping-pong forward, the ping-pong dQ and the role-split dK/dV kernels, which a launch
+                    // with causal == 2 selects)
+    int pad2;
 };
+// lower end of a row's visible keys, as an offset to add to the row index: `i + lv_band_low(dsc)` is the first visible key
+// (far below zero without a band)
+__device__ __forceinline__ int lv_band_low(const AttnDesc& d) { return d.band_p1 > 0 ? d.shift - (d.band_p1 - 1) : -(1 << 29); }

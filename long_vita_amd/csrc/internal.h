@@ -42,6 +42,7 @@ __device__ __forceinline__ AttnDesc lv_fwd_desc(const FwdParams& p, int blk, int
     d.a_rows = min(bm, p.q_rows_total - d.a_row0);
     d.b_row0 = 0;
     d.out_delta = 0;
+    d.band_p1 = 0;
     d.shift = causal ? p.k_rows_total - p.q_rows_total + d.a_row0 : 0;
     d.b_len = causal ? max(0, min(p.k_rows_total, d.a_rows + d.shift)) : p.k_rows_total;
     return d;

@@ -45,14 +45,14 @@ def _is_causal(atten_mask, sparse_mode, pre_tockens, next_tockens):
     raise NotImplementedError(f"sparse_mode={sparse_mode}")
 
 
-def _check_band(causal, sparse_mode, pre_tockens, longest):
-    """In band mode (sparse_mode 4, or 0 / 1 with a mask) the NPU op limits a query to the ``pre_tockens`` keys
-    before it; the kernels here have no band, so a segment longer than the band would silently see more keys than
-    the reference's op lets it.  Modes 2 / 3 ignore pre_tockens (the compressed causal template)."""
-    if causal and sparse_mode in (0, 1, 4) and pre_tockens is not None and longest > pre_tockens:
-        raise NotImplementedError(f"a segment of {longest} tokens exceeds pre_tockens={pre_tockens} in band mode "
-                                  f"(sparse_mode={sparse_mode}): banded causal attention is not built; raise "
-                                  "--pre-tockens to the sequence length or use sparse_mode 2")
+def _band(causal, sparse_mode, pre_tockens, longest):
+    """In its band modes (sparse_mode 4, or 0 / 1 with a mask) the NPU op limits a query to itself and the
+    ``pre_tockens`` keys before it (dot_product_attention.py:403-406 sets pre_tockens from --sliding-window, :462 passes
+    it); modes 2 / 3 ignore it (the compressed causal template).  Returns the band to apply, or None when no segment
+    is long enough to feel it."""
+    if causal and sparse_mode in (0, 1, 4) and pre_tockens is not None and 0 <= pre_tockens < longest - 1:
+        return int(pre_tockens)
+    return None
 
 
 def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, padding_mask=None, atten_mask=None,
@@ -73,8 +73,8 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
         if actual_seq_kvlen is not None and list(actual_seq_kvlen) != list(actual_seq_qlen):
             raise NotImplementedError("different q / kv segmentations are not supported")
         cu = ops.cu_seqlens_from_actual_seq_len(actual_seq_qlen)
-        _check_band(causal, sparse_mode, pre_tockens, max((b - a for a, b in zip(cu[:-1], cu[1:])), default=0))
-        out, lse = ops.varlen_attention(query, key, value, cu, scale, causal)
+        band = _band(causal, sparse_mode, pre_tockens, max((b - a for a, b in zip(cu[:-1], cu[1:])), default=0))
+        out, lse = ops.varlen_attention(query, key, value, cu, scale, causal, band)
         return out, lse, torch.ones_like(lse)
 
     if input_layout == "SBH":
@@ -87,8 +87,7 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
         v3 = value.reshape(value.shape[0], b * hkv, d)
         if k3.shape[0] != s:
             raise NotImplementedError("q and kv lengths differ")
-        _check_band(causal, sparse_mode, pre_tockens, s)
-        out, lse = ops.varlen_attention(q3, k3, v3, [0, s], scale, causal)
+        out, lse = ops.varlen_attention(q3, k3, v3, [0, s], scale, causal, _band(causal, sparse_mode, pre_tockens, s))
         return out.reshape(s, b, hd), lse, torch.ones_like(lse)
 
     if input_layout in ("BSH", "BSND", "BNSD"):
@@ -103,8 +102,7 @@ def npu_fusion_attention(query, key, value, head_num, input_layout, pse=None, pa
             d = hd // head_num
             to_t = lambda x: x.reshape(b * s, x.shape[2] // d, d)
         cu = [i * s for i in range(b + 1)]
-        _check_band(causal, sparse_mode, pre_tockens, s)
-        out, lse = ops.varlen_attention(to_t(query), to_t(key), to_t(value), cu, scale, causal)
+        out, lse = ops.varlen_attention(to_t(query), to_t(key), to_t(value), cu, scale, causal, _band(causal, sparse_mode, pre_tockens, s))
         if input_layout == "BNSD":
             out = out.reshape(b, s, -1, d).permute(0, 2, 1, 3)
         elif input_layout == "BSND":
@@ -157,9 +155,14 @@ def npu_prompt_flash_attention(query, key, value, num_heads=1, input_layout="BSH
     d, hkv = _kv_heads(query, key, num_heads, num_key_value_heads)
     if sk < sq:
         raise ValueError("fewer keys than queries")
+    band = _band(causal, sparse_mode if atten_mask is not None else 0, pre_tokens, sk)
     outs = []
     for i in range(b):      # one rectangle per sequence; the views keep the caller's strides
         q3, k3, v3 = query[i].unflatten(1, (num_heads, d)), key[i].unflatten(1, (hkv, d)), value[i].unflatten(1, (hkv, d))
+        if band is not None:    # the band bounds every row's sweep: no need to cut the key range
+            desc = ops.rect_band_blocks_on_device(0, sq, 0, sk, sk - sq, band, q3.device)
+            outs.append(ops.attn_fwd_launch(q3, k3, v3, desc, scale_value, 2)[0].reshape(sq, hd))
+            continue
         # a short new block against a long cache is cut along the keys so that it fills the chip (ops.attn_fwd_rect_split_keys)
         outs.append(ops.attn_fwd_rect_split_keys(q3, k3, v3, scale_value, causal, sk - sq)[0].reshape(sq, hd))
     return torch.stack(outs)

@@ -134,6 +134,38 @@ def rect_blocks_on_device(q_row0, q_len, k_row0, k_len, causal, shift, backward,
     return _blocks.get(key, lambda: _to_device(build_rect_blocks_host(q_row0, q_len, k_row0, k_len, causal, shift, backward), device))
 
 
+def band_blocks_on_device(cu_seqlens: Sequence[int], band: int, backward: bool, device) -> torch.Tensor:
+    """Descriptors of packed segments under a band (a query sees itself and the ``band`` keys before it): launch them with
+    causal = 2."""
+    key = ("band", tuple(int(x) for x in cu_seqlens), int(band), bool(backward), str(device), _block_rows(backward))
+
+    def build():
+        cu = np.ascontiguousarray(np.asarray(cu_seqlens, dtype=np.int32))
+        n_seg = cu.shape[0] - 1
+        blk = LV_BWD_BLOCK_N if backward else _lib.lib().lvattn_fwd_block_m()
+        lens = np.diff(cu.astype(np.int64)) if n_seg else np.zeros(0, np.int64)
+        max_blocks = int(np.sum((np.maximum(lens, 0) + blk - 1) // blk)) + 1
+        out = np.zeros((max_blocks, LV_DESC_INTS), dtype=np.int32)
+        fn = _lib.lib().lv_build_bwd_blocks_band if backward else _lib.lib().lv_build_fwd_blocks_band
+        n = check(fn(cu.ctypes.data_as(_I32P), n_seg, int(band), out.ctypes.data_as(_I32P), max_blocks), "lv_build_blocks_band")
+        return _to_device(out[:n], device)
+    return _blocks.get(key, build)
+
+
+def rect_band_blocks_on_device(q_row0, q_len, k_row0, k_len, shift, band, device) -> torch.Tensor:
+    """Forward descriptors of one rectangle under a band (the prompt pass over a KV cache)."""
+    key = ("rect_band", q_row0, q_len, k_row0, k_len, shift, int(band), str(device), _block_rows(False))
+
+    def build():
+        blk = _lib.lib().lvattn_fwd_block_m()
+        max_blocks = (q_len + blk - 1) // blk + 1
+        out = np.zeros((max_blocks, LV_DESC_INTS), dtype=np.int32)
+        n = check(_lib.lib().lv_build_fwd_blocks_rect_band(q_row0, q_len, k_row0, k_len, shift, int(band), out.ctypes.data_as(_I32P), max_blocks),
+                  "lv_build_fwd_blocks_rect_band")
+        return _to_device(out[:n], device)
+    return _blocks.get(key, build)
+
+
 def rects_blocks_on_device(rects, backward: bool, device) -> torch.Tensor:
     """Descriptors for several rectangles of one launch: ``rects`` = tuples (q_row0, q_len, k_row0, k_len, shift), all
     causal with their own shift (key j of the rectangle visible to its row i iff j <= i + shift; a shift >= k_len makes
@@ -470,8 +502,20 @@ def attn_bwd_split_launch(q, k, v, out, dout, lse, tq: SplitTables, tk: SplitTab
 # ---------------------------------------------------------------------------
 class _VarlenAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, cu_seqlens, scale, causal):
+    def forward(ctx, q, k, v, cu_seqlens, scale, causal, band=None):
         total = q.shape[0]
+        ctx.band = band
+        if band is not None:      # banded causal attention: its own tables, launched with causal = 2
+            if not causal:
+                raise LvAttnError("a band needs causal attention")
+            desc = band_blocks_on_device(cu_seqlens, band, False, q.device)
+            out = torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+            lse = torch.full((q.shape[1], total), float("-inf"), dtype=torch.float32, device=q.device)
+            out, lse = attn_fwd_launch(q, k, v, desc, scale, 2, out, lse)
+            ctx.save_for_backward(q, k, v, out, lse)
+            ctx.cu_seqlens, ctx.scale, ctx.causal, ctx.pieces = tuple(cu_seqlens), scale, causal, (0, 0)
+            ctx.mark_non_differentiable(lse)
+            return out, lse
         # few work items for the chip (small head counts, short batches): cut the sweeps into pieces
         ctx.pieces = plan_split(cu_seqlens, causal, q.shape[1], k.shape[1], q.device) if q.is_cuda else (0, 0)
         ctx.covered = len(cu_seqlens) > 1 and cu_seqlens[0] == 0 and cu_seqlens[-1] == total == k.shape[0]
@@ -496,24 +540,35 @@ class _VarlenAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dlse):
         q, k, v, out, lse = ctx.saved_tensors
+        if ctx.band is not None:
+            desc_q = band_blocks_on_device(ctx.cu_seqlens, ctx.band, False, q.device)
+            desc_k = band_blocks_on_device(ctx.cu_seqlens, ctx.band, True, q.device)
+            dq, dk, dv, _ = attn_bwd_launch(q, k, v, out, dout, lse, desc_q, desc_k, ctx.scale, 2)
+            return dq, dk, dv, None, None, None, None
         pf, pb = ctx.pieces
         if pf > 0 or pb > 0:      # one launch takes one kind of output buffer: when either sweep is cut, both go through workspaces
             tq = split_tables_on_device(ctx.cu_seqlens, ctx.causal, False, pf if pf > 0 else _ONE_PIECE, q.device)
             tk = split_tables_on_device(ctx.cu_seqlens, ctx.causal, True, pb if pb > 0 else _ONE_PIECE, q.device)
             dq, dk, dv = attn_bwd_split_launch(q, k, v, out, dout, lse, tq, tk, ctx.scale, ctx.causal, ctx.covered)
-            return dq, dk, dv, None, None, None
+            return dq, dk, dv, None, None, None, None
         desc_q = blocks_on_device(ctx.cu_seqlens, ctx.causal, False, q.device)
         desc_k = blocks_on_device(ctx.cu_seqlens, ctx.causal, True, q.device)
         dq, dk, dv, _ = attn_bwd_launch(q, k, v, out, dout, lse, desc_q, desc_k, ctx.scale, ctx.causal)
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
 
 
-def varlen_attention(q, k, v, cu_seqlens: Sequence[int], scale: float | None = None, causal: bool = True):
+def varlen_attention(q, k, v, cu_seqlens: Sequence[int], scale: float | None = None, causal: bool = True, band: int | None = None):
     """Packed variable-length attention, one block per segment of ``cu_seqlens``.
-    q [T,Hq,D], k/v [T,Hkv,D] bf16 -> (out [T,Hq,D] bf16, lse [Hq,T] fp32); differentiable in q, k, v."""
+    q [T,Hq,D], k/v [T,Hkv,D] bf16 -> (out [T,Hq,D] bf16, lse [Hq,T] fp32); differentiable in q, k, v.
+    ``band`` (causal only): a query sees itself and the ``band`` keys before it (the fused op's band modes,
+    dot_product_attention.py:403-406, 454-467); a band no segment is longer than changes nothing and is dropped."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
-    return _VarlenAttention.apply(q, k, v, tuple(int(x) for x in cu_seqlens), float(scale), bool(causal))
+    cu = tuple(int(x) for x in cu_seqlens)
+    if band is not None:
+        longest = max((b - a for a, b in zip(cu[:-1], cu[1:])), default=0)
+        band = int(band) if int(band) < longest - 1 else None
+    return _VarlenAttention.apply(q, k, v, cu, float(scale), bool(causal), band)
 
 
 # ---------------------------------------------------------------------------

@@ -132,12 +132,24 @@ def block_attention(q, k, v, scale: float, mask: np.ndarray | None):
     return out, lse
 
 
-def varlen_attention(q, k, v, cu_seqlens, scale: float, causal: bool = True):
+def segment_mask(L: int, causal: bool, band: int | None = None):
+    """Boolean [L, L] mask of one segment, True = masked: keys after the query when ``causal``; with ``band`` also keys
+    more than ``band`` positions before it (what pre_tockens / --sliding-window ask of the fused op in its band modes,
+    dot_product_attention.py:403-406, 454-467: a query sees itself and the ``band`` keys before it)."""
+    if not causal:
+        return None
+    mask = np.triu(np.ones((L, L), dtype=bool), 1)
+    if band is not None:
+        mask |= np.tril(np.ones((L, L), dtype=bool), -int(band) - 1)
+    return mask
+
+
+def varlen_attention(q, k, v, cu_seqlens, scale: float, causal: bool = True, band: int | None = None):
     """Packed variable-length attention, one (causal) block per segment.
 
     q [T,Hq,D], k/v [T,Hkv,D] ("TND"); ``cu_seqlens`` = [0] + the reference's
     ``actual_seq_len`` cumulative end offsets
-    (dot_product_attention.py:345-365: sparse_mode=2 + actual_seq_qlen)."""
+    (dot_product_attention.py:345-365: sparse_mode=2 + actual_seq_qlen).  ``band``: see ``segment_mask``."""
     q, k, v = _f64(q), _f64(k), _f64(v)
     T, Hq, D = q.shape
     out = np.zeros((T, Hq, v.shape[2]))
@@ -147,14 +159,14 @@ def varlen_attention(q, k, v, cu_seqlens, scale: float, causal: bool = True):
         if b <= a:
             continue
         L = b - a
-        mask = np.triu(np.ones((L, L), dtype=bool), 1) if causal else None
+        mask = segment_mask(L, causal, band)
         o, s = block_attention(q[a:b], k[a:b], v[a:b], scale, mask)
         out[a:b] = o
         lse[:, a:b] = s
     return out, lse
 
 
-def varlen_attention_grad(q, k, v, dout, cu_seqlens, scale: float, causal: bool = True):
+def varlen_attention_grad(q, k, v, dout, cu_seqlens, scale: float, causal: bool = True, band: int | None = None):
     """float64 gradients of ``varlen_attention`` w.r.t. q, k, v for upstream
     gradient ``dout`` [T,Hq,D] (the ``npu_fusion_attention_grad`` the reference
     reaches through autograd).  Textbook softmax-attention backward:
@@ -172,7 +184,7 @@ def varlen_attention_grad(q, k, v, dout, cu_seqlens, scale: float, causal: bool 
         L = b - a
         if L <= 0:
             continue
-        mask = np.triu(np.ones((L, L), dtype=bool), 1) if causal else None
+        mask = segment_mask(L, causal, band)
         for h in range(Hq):
             g = h // rep
             s = (q[a:b, h] @ k[a:b, g].T) * scale

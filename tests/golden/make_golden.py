@@ -28,6 +28,8 @@ Fixtures written:
                        run over the oracle's restatement of the Megatron submodules
   eager_attention_grad.npz  the same eager wrapper with torch autograd through it (dq / dk / dv), causal and
                        block-diagonal-causal (packed segments) masks, more than one 256-row query block
+  eager_attention_band.npz  the eager wrapper + autograd under band masks (causal, and keys more than `band` positions
+                       before the query masked too: pre_tockens / --sliding-window), plain and packed
   embedding_scatter.npz  LanguageModelEmbedding.forward (language_model_embedding.py:91-174) in bf16 with autograd:
                        the visual-feature scatter in its indices / pre_len / src+tgt / no-indices forms
 """
@@ -231,6 +233,62 @@ def gen_eager_attention_grad():
         out[f"{name}.dq"], out[f"{name}.dk"], out[f"{name}.dv"] = qf.grad.numpy(), kf.grad.numpy(), vf.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "eager_attention_grad.npz"), **out)
     print("eager_attention_grad.npz:", len(out), "arrays")
+
+
+def gen_eager_attention_band():
+    """Outputs and autograd gradients of the reference's eager wrapper under BAND masks: causal, and a key more than
+    ``band`` positions before the query masked as well (what pre_tockens / --sliding-window ask of the fused op,
+    dot_product_attention.py:403-406, 454-467; the eager wrapper takes any mask), plain and packed."""
+    dpa = importlib.import_module("lcvlm_modellink.core.transformer.dot_product_attention")
+
+    def smsoftmax(scores, mask):   # Megatron FusedScaleMaskSoftmax, unfused fp32 path (not in the reference tree; restated)
+        x = scores.float()
+        if mask is not None:
+            x = x.masked_fill(mask, -10000.0)
+        return torch.softmax(x, dim=-1).to(scores.dtype)
+
+    dpa.get_args = lambda: ns(use_flash_attn=False)
+    dpa.parallel_state = ns(get_global_memory_buffer=lambda: ns(
+        get_tensor=lambda shape, dtype, name: torch.empty(shape, dtype=dtype)))
+    dpa.tensor_parallel = ns(get_cuda_rng_tracker=lambda: ns(fork=contextlib.nullcontext))
+    wrapper = dpa.dot_product_attention_forward_wrapper(lambda *a, **k: None)
+    cases = [
+        # name, sq, np, ng, hn, cu_seqlens (None = one segment), band
+        ("band_causal", 420, 5, 1, 128, None, 100),
+        ("band_packed", 520, 2, 1, 128, [0, 200, 201, 520], 64),
+        ("band_d64", 300, 4, 2, 64, None, 37),
+        ("band_self_only", 70, 2, 1, 64, None, 0),
+        ("band_wider_than_rows", 140, 2, 1, 128, None, 500),
+    ]
+    g = torch.Generator().manual_seed(20250303)
+    out = {}
+    for name, sq, np_, ng, hn, cu, band in cases:
+        q = torch.randn(sq, 1, np_, hn, generator=g).to(torch.bfloat16)
+        k = torch.randn(sq, 1, ng, hn, generator=g).to(torch.bfloat16)
+        v = torch.randn(sq, 1, ng, hn, generator=g).to(torch.bfloat16)
+        do = torch.randn(sq, 1, np_ * hn, generator=g).to(torch.bfloat16)
+        qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+        ones = torch.ones(sq, sq, dtype=torch.bool)
+        mask = torch.triu(ones, 1) | torch.tril(ones, -band - 1)     # True = masked: key after the row, or more than `band` before it
+        if cu is not None:
+            seg = torch.zeros(sq, dtype=torch.long)
+            for i, (a, b) in enumerate(zip(cu[:-1], cu[1:])):
+                seg[a:b] = i
+            mask = mask | (seg[:, None] != seg[None, :])
+        self = ns(num_attention_heads_per_partition=np_, num_query_groups_per_partition=ng,
+                  alibi=None, norm_factor=float(hn) ** 0.5, attn_logit_softcapping=None,
+                  square_alibi_mask=False, scale_mask_softmax=smsoftmax,
+                  config=ns(sequence_parallel=True), attention_dropout=lambda x: x,
+                  hidden_size_per_partition=np_ * hn)
+        o = wrapper(self, qf, kf, vf, mask[None, None], None, None)
+        o.backward(do.float())
+        out[f"{name}.meta"] = np.array([sq, np_, ng, hn, band], dtype=np.int64)
+        out[f"{name}.cu"] = np.array(cu if cu is not None else [0, sq], dtype=np.int64)
+        out[f"{name}.q"], out[f"{name}.k"], out[f"{name}.v"], out[f"{name}.dout"] = map(_bf16_bits, (q, k, v, do))
+        out[f"{name}.out"] = _bf16_bits(o.detach())          # (stored as bf16: the comparison's tolerance is 2e-2)
+        out[f"{name}.dq"], out[f"{name}.dk"], out[f"{name}.dv"] = (x.grad.numpy().astype(np.float16) for x in (qf, kf, vf))
+    np.savez_compressed(os.path.join(HERE, "eager_attention_band.npz"), **out)
+    print("eager_attention_band.npz:", len(out), "arrays")
 
 
 def gen_embedding_scatter():
@@ -654,11 +712,13 @@ def gen_vit():
 
 if __name__ == "__main__":
     install_shim()
-    which = sys.argv[1:] or ["eager", "eager_grad", "embedding", "indexing", "pixel_shuffle_v2", "packing", "rope", "vit"]
+    which = sys.argv[1:] or ["eager", "eager_grad", "eager_band", "embedding", "indexing", "pixel_shuffle_v2", "packing", "rope", "vit"]
     if "eager" in which:
         gen_eager_attention()
     if "eager_grad" in which:
         gen_eager_attention_grad()
+    if "eager_band" in which:
+        gen_eager_attention_band()
     if "embedding" in which:
         gen_embedding_scatter()
     if "indexing" in which:

@@ -414,19 +414,6 @@ def test_operands_of_the_elementwise_kernels_are_validated():
     ops.layernorm_launch(x, good, good, 1e-5)          # the well-formed call still goes through
 
 
-def test_band_mode_longer_than_pre_tockens_raises():
-    from long_vita_amd.fusion_attention import npu_fusion_attention
-    q = torch.zeros(512, 2, 128, dtype=torch.bfloat16, device="cuda")
-    with pytest.raises(NotImplementedError):
-        npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=4,
-                             actual_seq_qlen=[512], actual_seq_kvlen=[512])
-    npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=4,
-                         actual_seq_qlen=[256, 512], actual_seq_kvlen=[256, 512])
-    npu_fusion_attention(q, q, q, 2, "TND", atten_mask=True, scale=1.0, pre_tockens=256, next_tockens=0, sparse_mode=2,
-                         actual_seq_qlen=[512], actual_seq_kvlen=[512])
-
-
-
 def test_tensor_of_another_device_is_refused(monkeypatch):
     """The launches go to the current device's current stream: a tensor that lives on another GPU must raise instead of
     being addressed from the wrong device (one-GPU box: the current device index is faked)."""

@@ -232,3 +232,26 @@ def test_sampled_gradient_rows_equal_the_full_float64_backward():
                 assert np.abs(dk.numpy() - rdk[j, gkv]).max() < 1e-12 and np.abs(dv.numpy() - rdv[j, gkv]).max() < 1e-12
     assert R.row_excess(torch.tensor([1.0, 0.0]), torch.tensor([1.0, 0.0])) == 0.0
     assert R.row_excess(torch.tensor([1.03, 0.0]), torch.tensor([1.0, 0.0])) > 1.0
+
+
+def _bf16_from_bits(bits):
+    return torch.from_numpy(bits.astype(np.int16)).view(torch.bfloat16)
+
+
+def test_band_masked_attention_oracle_against_reference_wrapper(golden_dir):
+    """The float64 oracle with a band (a query sees itself and the `band` keys before it, inside its segment) against
+    outputs and autograd gradients of the reference's eager wrapper under the same masks (eager_attention_band.npz)."""
+    g = np.load(os.path.join(golden_dir, "eager_attention_band.npz"))
+    for name in ("band_causal", "band_packed", "band_d64", "band_self_only", "band_wider_than_rows"):
+        sq, np_, ng, hn, band = (int(x) for x in g[f"{name}.meta"])
+        cu = [int(x) for x in g[f"{name}.cu"]]
+        q, k, v = (_bf16_from_bits(g[f"{name}.{x}"])[:, 0] for x in "qkv")
+        do = _bf16_from_bits(g[f"{name}.dout"])[:, 0].reshape(sq, np_, hn)
+        scale = A.default_scale(hn)
+        out, _ = A.varlen_attention(q, k, v, cu, scale, True, band=band)
+        dq, dk, dv = A.varlen_attention_grad(q, k, v, do, cu, scale, True, band=band)
+        ref_out = _bf16_from_bits(g[f"{name}.out"]).double().numpy().reshape(sq, np_, hn)
+        assert np.abs(out - ref_out).max() <= 8e-3 * np.abs(ref_out).max(), name       # the fixture's out is stored in bf16
+        for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+            ref = g[f"{name}.{key}"].astype(np.float64)[:, 0]                            # stored in fp16
+            assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6), (name, key)
