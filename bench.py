@@ -467,7 +467,7 @@ def main():
         achieved = flops_per_gpu_step / mean_kernel_s / 1e12
         traffic, traffic_note = None, None
         if wl == "prefill_1m" and not args.seq and world == 1:
-            traffic, traffic_note = profiled_traffic("r02_prefill_1m_pmc_summary.json", "lv_fwd_a4_kernel<true>")
+            traffic, traffic_note = profiled_traffic("r03_prefill_1m_pmc_summary.json", "lv_fwd_a4_kernel<true>")
         res = {
             "metric": ("attention prefill tokens/sec (node) at 1M ctx" if not args.seq else f"attention prefill tokens/sec (node) at {S} ctx")
             if wl == "prefill_1m" else f"attention tokens/sec ({wl})",
