@@ -236,7 +236,16 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 
     // pipeline state carried from one iteration to the next (the dO rows of the current unit are in a[224:255])
     f32x16 sv;            // S of the current unit until gap 7, of the next one from gap 8
-    f32x4 l4[4];          // the current unit's lse (natural log), rows 8 g + 4 h .. + 3
+    f32x16 dp;            // -delta of the current unit's rows at the start of an iteration: the dP product accumulates onto it
+    f32x4 l4[4];          // the current unit's -lse * log2(e), rows 8 g + 4 h .. + 3
+
+    // The staged row constants are lse (natural log) and delta.  What the loop wants is -lse * log2(e) (so that P is one
+    // fused multiply-add and one exponential per score) and -delta (the initial accumulator of the dP product, so that dS
+    // is one multiply): the wave that requested a unit's constants rewrites them in place, one float per lane, two
+    // iterations before their first reader (a barrier lies between).
+    const float resc_mul = (lane < 32) ? -1.4426950408889634f : -1.f;
+    lds_char* const resc_ptr = lds0 + 2 * QTILE + 4 * lane;
+    int it_n = 0;         // iterations started so far = number of the current unit
 
     int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
 
@@ -252,17 +261,19 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         if (++c_hg == p.group) { c_hg = 0; --c_sl; }
         const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
 
-        // Everything older than the last three iterations' requests has landed (this wave's share of unit u+1); the
+        // Everything older than the last two iterations' requests has landed (this wave's share of unit u+2); the
         // barrier makes that true of every wave's share, and tells this wave that all waves are done with the slot of
         // unit u-1, which this iteration's requests overwrite.  No LDS read is left in flight either (the dO rows and
         // the lse of this unit were read at the end of the last iteration).
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(3 * PPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 
         bf16x8 doT[2 * MT], qT[2 * MT];   // transposed fragments (s2, mt) of this unit, each alive for about four gaps
-        f32x4 d4[4];              // delta of this unit
-        f32x16 dp;
         float pv[16];
+        constexpr int RS = (SLOT + 2) % NBUF;         // slot of unit u+2, whose constants wave (u+2) mod 4 rescales now
+        const bool resc_mine = ((it_n + 2) & 3) == w;
+        ++it_n;
+        float resc_val = 0.f;
         bf16x8 pf[2], dsf[2];
 
         auto tr_read = [&](bf16x8& f, int set, int off, int mt) __attribute__((always_inline)) {
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             constexpr int k = decltype(K_)::value;
             // ---- the MFMA of this gap
             if constexpr (k < 8) {
-                g_mfma_x<g_OA(k), g_VF(k), k == 0, -1>(dp);
+                g_mfma_x<g_OA(k), g_VF(k), false, -1>(dp);       // onto -delta
             } else if constexpr (k < 16) {
                 g_mfma_x<g_QA(k - 8), g_KF(k - 8), k == 8, g_qa_wait(k - 8)>(sv);
             } else if constexpr (k < 24) {
@@ -294,9 +305,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 a4_read_k<g_QA(2 * (k - 4)), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4)) << 5));
                 a4_read_k<g_QA(2 * (k - 4) + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4) + 1) << 5));
             }
-            if constexpr (k >= 8 && k < 12) {       // delta of unit u, for gaps 12-19
-                d4[k - 8] = *(LDS_PTR(f32x4, c_ptr[CS] + CO + 128 + 32 * (k - 8)));
-            }
+            if constexpr (k == 0) { if (resc_mine) resc_val = *(LDS_PTR(float, resc_ptr + RS * SLOTB)); }
+            if constexpr (k == 3) { if (resc_mine) *(LDS_PTR(float, resc_ptr + RS * SLOTB)) = resc_val * resc_mul; }
             if constexpr (k >= 12 && k < 20) {      // dO^T of unit u, fragment k - 12, needed in gap 16 + (k - 12)
                 constexpr int j = k - 12, s2 = j / MT, mt = j % MT;
                 tr_read(doT[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
@@ -308,8 +318,12 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             if constexpr (k >= 16 && k < 24) {      // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
                 a4_read_k<g_OA(k - 16), NO + QTILE>(a_addr[NS] ^ (uint32_t)((k - 16) << 5));
             }
-            if constexpr (k >= 24 && k < 28) {      // lse of unit u+1 (this unit's was last read in gap 7)
+            if constexpr (k >= 24 && k < 28) {      // -lse2 of unit u+1 (this unit's was last read in gap 7)
                 l4[k - 24] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 24)));
+            }
+            if constexpr (k >= 28) {                // -delta of unit u+1: where its dP product starts (dP of this unit was last read in gap 19)
+                const f32x4 t4 = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 128 + 32 * (k - 28)));
+                dp[4 * (k - 28)] = t4[0]; dp[4 * (k - 28) + 1] = t4[1]; dp[4 * (k - 28) + 2] = t4[2]; dp[4 * (k - 28) + 3] = t4[3];
             }
 
             // ---- P(u): two scores per gap in gaps 0-7, the (rare) mask in gap 8, packed in gaps 8-11
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 2 * k + e;
-                    pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, -1.4426950408889634f * l4[i >> 2][i & 3]));
+                    pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, l4[i >> 2][i & 3]));
                 }
             }
             if constexpr (k == 8) {
@@ -337,12 +351,13 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 pf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; pf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
                 if constexpr (k == 9 || k == 11) asm volatile("" : "+v"(pf[(k - 8) >> 1]));   // formed here, not next to its use
             }
-            // ---- dS(u) = P (dP - delta): two values per gap in gaps 12-19 (dP is complete after gap 7), packed in 20-23
+            // ---- dS(u) = P (dP - delta): two values per gap in gaps 12-19 (the product started from -delta and is complete
+            // after gap 7), packed in 20-23
             if constexpr (k >= 12 && k < 20) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 2 * (k - 12) + e;
-                    pv[i] = pv[i] * (dp[i] - d4[i >> 2][i & 3]);
+                    pv[i] = pv[i] * dp[i];
                 }
             }
             if constexpr (k >= 20 && k < 24) {
@@ -364,13 +379,22 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) { dma_pieces(i); dma_consts_and_advance(i); }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (w < 2) {       // constants of units 0 and 1 (iteration 0 takes over from unit 2)
+            const float t = *(LDS_PTR(float, resc_ptr + w * SLOTB));
+            *(LDS_PTR(float, resc_ptr + w * SLOTB)) = t * resc_mul;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) {
             constexpr int ks = decltype(I_)::value;
             a4_read_k<g_QA(ks), 0>(a_addr[0] ^ (uint32_t)(ks << 5));
             a4_read_k<g_OA(ks), QTILE>(a_addr[0] ^ (uint32_t)(ks << 5));
         });
 #pragma unroll
-        for (int g = 0; g < 4; ++g) l4[g] = *(LDS_PTR(f32x4, c_ptr[0] + 32 * g));
+        for (int g = 0; g < 4; ++g) {
+            l4[g] = *(LDS_PTR(f32x4, c_ptr[0] + 32 * g));
+            const f32x4 t4 = *(LDS_PTR(f32x4, c_ptr[0] + 128 + 32 * g));
+            dp[4 * g] = t4[0]; dp[4 * g + 1] = t4[1]; dp[4 * g + 2] = t4[2]; dp[4 * g + 3] = t4[3];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) {
