@@ -152,7 +152,8 @@ int lv_mean_keys_per_item(const int32_t* desc_host, int n_blocks);
  * "pp16", "lockstep"; the same names as the LVATTN_FWD_KERNEL environment variable, which is read on first use
  * otherwise). */
 int lvattn_select_fwd_kernel(const char* name);
-/* The same for the backward: dq in {"default", "pp", "lockstep"}, dkdv in {"default", "rs" (role-split, two units per
+/* The same for the backward: dq in {"default", "pp", "lockstep"}, dkdv in {"default" (the gap-scheduled one-wave kernel
+ * at head dim 128, the role-split kernel at head dim 64 and for banded descriptors), "g", "rs" (role-split, two units per
  * iteration), "rs1" (one unit), "single"} -- LVATTN_DQ_KERNEL / LVATTN_DKDV_KERNEL / LVATTN_DKDV_UNITS otherwise. */
 int lvattn_select_bwd_kernels(const char* dq, const char* dkdv);
 

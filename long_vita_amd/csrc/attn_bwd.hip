@@ -631,16 +631,18 @@ static bool dq_pingpong() {
     return g_dq_kernel == 0;
 }
 
-// dK/dV kernel choice: the role-split kernel (attn_bwd_dkdv_rs.hip) unless the environment variable
-// LVATTN_DKDV_KERNEL=single asks for the one-wave-per-SIMD kernel in this file.
-static int dkdv_choice() {   // 0 role-split (default), 1 the kernel in this file, 2 the gap-scheduled one-wave kernel (d = 128)
+// dK/dV kernel choice.  Left to the library: the gap-scheduled one-wave kernel (attn_bwd_dkdv_g.hip) at head dim 128
+// (same-box A/B, 131,072 tokens, forward + backward: one segment 630.0 -> 618.3 ms, packed segments 72.3 -> 71.0 ms, packed
+// at 5 / 1 heads 9.81 -> 9.70 ms), the role-split kernel (attn_bwd_dkdv_rs.hip) at head dim 64 and for descriptors with a
+// band.  The environment variable LVATTN_DKDV_KERNEL = rs / g / single forces one.
+static int dkdv_choice() {   // 0 the library's choice, 1 the first-generation kernel in this file, 2 gap-scheduled (d = 128), 3 role-split
     if (g_dkdv_kernel < 0) {
         const char* e = getenv("LVATTN_DKDV_KERNEL");
-        g_dkdv_kernel = (e && !strcmp(e, "single")) ? 1 : (e && !strcmp(e, "g")) ? 2 : 0;
+        g_dkdv_kernel = (e && !strcmp(e, "single")) ? 1 : (e && !strcmp(e, "g")) ? 2 : (e && !strcmp(e, "rs")) ? 3 : 0;
     }
     return g_dkdv_kernel;
 }
-// run-time override of the two choices above: 0 default, 1 the kernel in this file, < 0 leave as it is
+// run-time override of the two choices above: 0 default, 1 the kernel in this file (dkdv: 2 / 3 as in dkdv_choice), < 0 leave as it is
 void lv_select_bwd_kernels(int dq, int dkdv) {
     if (dq >= 0) g_dq_kernel = dq;
     if (dkdv >= 0) g_dkdv_kernel = dkdv;
@@ -653,7 +655,7 @@ static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stre
     causal = causal != 0;
     if (p.n_blocks > 0 && banded) {
         lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);
-    } else if (p.n_blocks > 0 && dkdv_choice() == 2 && D == 128) {
+    } else if (p.n_blocks > 0 && (dkdv_choice() == 2 || dkdv_choice() == 0) && D == 128) {
         lv_launch_bwd_dkdv_g(p, causal, accum, stream);
     } else if (p.n_blocks > 0 && dkdv_choice() != 1) {
         lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);

@@ -4,34 +4,31 @@
 // One workgroup = 4 waves = one 128-key block of one K/V head; wave w keeps the K and V fragments and the dK^T and dV^T
 // accumulators of ITS 32 keys (key on the lane) in the 512 registers a lone wave of a SIMD has, while the workgroup
 // sweeps "units" (a 32-row query slice of one query head of the group; slices last to first, heads inside), staged in
-// a six-slot LDS ring by direct global -> LDS loads.  Same arithmetic and accumulation order as the first-generation kernel of attn_bwd.hip:
-// S = Q K^T, P = exp2(c S - lse2), dV^T += dO^T P, dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS.
+// an LDS ring by direct global -> LDS loads.  Same arithmetic and accumulation order as the first-generation kernel of
+// attn_bwd.hip: S = Q K^T, P = exp2(c S - lse2), dV^T += dO^T P, dP = dO V^T, dS = P (dP - delta), dK^T += Q^T dS.
 //
 // What differs is the instruction stream.  A lone wave issues everything its SIMD runs, about one instruction per four
-// cycles (an exponential eight), and a v_mfma_f32_32x32x16_bf16 keeps the matrix pipe busy for 32: an iteration (one
-// unit, 32 MFMAs, ONE workgroup barrier) is written as 32 "gaps", each holding its MFMA followed by a fixed, small
-// share of the other work, and a scheduling barrier after every gap keeps the compiler from packing the MFMAs together
-// and the vector work behind them.  Software pipeline of iteration u:
-//   gaps  0- 7  dP(u)    = dO(u) V^T  (onto -delta)| P(u): one exponential per gap (two in 4, 5) | Q(u+1) rows (0-3)
-//   gaps  8-15  S(u+1)   = Q(u+1) K^T              | P(u) to 13; pack P; dS(u) = P dP from 10    | dO(u+1) rows (8-11), dO^T(u) from 12
-//   gaps 16-23  dV^T    += dO^T(u) P(u)            | dS(u), pack                                 | dO^T(u), Q^T(u) from 20
-//   gaps 24-31  dK^T    += Q^T(u) dS(u)            |                                             | Q^T(u), constants of u+1 (28-31)
-// The staging requests of unit u+5 (four 1-KiB pieces per wave) sit in gaps 2, 10, 18 and 26: the workgroup's sixteen
-// pieces share one address path that takes about sixteen cycles per piece, and a wave whose request finds it busy
-// waits in issue (all four pieces in one gap cost a sixth of the loop).  The scores of successive units alternate
-// between two register blocks (P overwrites S in place), which is what lets the exponentials spread over fourteen gaps.
+// cycles, and a v_mfma_f32_32x32x16_bf16 keeps the matrix pipe busy for 32: an iteration (one unit, 32 MFMAs, ONE
+// workgroup barrier) is written as 32 "gaps", each holding its MFMA followed by a fixed share of the other work --
+// exponentials, dS, bf16 packing, the LDS fragment reads of later gaps, the staging requests -- and a scheduling
+// barrier after every gap keeps the compiler from packing the MFMAs together and the vector work behind them.
+// Software pipeline of iteration u:
+//   gaps  0- 7  dP(u)    = dO(u) V^T          | P(u) = exp2(c S(u) - lse2(u))   | read Q(u+1) rows, delta(u), dO^T(u)
+//   gaps  8-15  S(u+1)   = Q(u+1) K^T         | pack P(u); dS(u) = P (dP - delta)| read dO^T(u), Q^T(u)
+//   gaps 16-23  dV^T    += dO^T(u) P(u)       | dS(u), pack                      | read Q^T(u), dO(u+1) rows
+//   gaps 24-31  dK^T    += Q^T(u) dS(u)       | staging requests of unit u+5     | read dO(u+1) rows, lse2(u+1)
 // The loop is unrolled over the six ring slots, so every LDS address is a lane register plus an immediate.
 //
 // Register file, laid out by hand as in the one-wave forward kernel (attn_fwd_a4.hip): the accumulator half holds
 //   a[0:63] dV^T (tile mt at 16 mt)   a[64:127] dK^T   a[128:159] K fragments   a[160:191] V fragments
 //   a[192:223] Q rows of the next unit   a[224:255] dO rows of the current unit (both read from LDS straight into place)
 // and is touched only by the asm statements here (MFMAs naming those registers, ds_read_b128 into them, the epilogue);
-// the vector half (scores, P, dS, transposed fragments, row constants, addresses) is the compiler's, and so are the
-// waits of the LDS reads it makes itself.  Left to itself the allocator does not split such a kernel over the two
-// halves: the plain-builtin form of this loop spilled 583 registers.  The compiler neither counts nor pads what is
-// inside an asm statement: LDS reads into the accumulator half are waited for by counted s_waitcnt inside the MFMA
-// statement that needs them, and the wait states (an MFMA result -> a vector reader: 12; a vector write -> an MFMA
-// operand: 2) hold by construction of the gap schedule (every such pair is at least two gaps apart).
+// the vector half (scores, P, dS, transposed fragments, row constants, addresses) is the compiler's.  Left to itself
+// the allocator does not split such a kernel over the two halves: the plain-builtin form of this loop spilled 583
+// registers.  The compiler neither counts nor pads what is inside an asm statement: LDS reads into the accumulator half
+// are waited for by counted s_waitcnt inside the MFMA statement that needs them, and the wait states (an MFMA result ->
+// a vector reader: 12; a vector write -> an MFMA operand: 2) hold by construction of the gap schedule (every such pair
+// is at least three gaps apart).
 #include "a4_asm.h"
 
 namespace {
@@ -52,14 +49,14 @@ __device__ constexpr int g_VF(int ks) { return 160 + 4 * ks; }
 __device__ constexpr int g_QA(int ks) { return 192 + 4 * ks; }
 __device__ constexpr int g_OA(int ks) { return 224 + 4 * ks; }
 
-// LDS operations of gap k that every wave issues (asm and compiler's alike): Q rows, dO rows, transposed fragments,
-// row constants
-__device__ constexpr int g_lds_ops(int k) { return (k >= 4 && k < 8) ? 0 : 2; }
-// LDS operations that may still be in flight when the MFMA of gap 8 + j takes Q-row fragment j, read in gap j / 2: all
-// those of the gaps after that one (the order inside a gap is the compiler's, so none of its own gap is counted)
+// LDS operations of gap k that every wave issues (asm and compiler's alike) between the Q-row reads and their use: the
+// Q rows themselves (two per gap in gaps 4-7), the transposed dO fragments (two 8-byte reads per gap from gap 12 on)
+__device__ constexpr int g_lds_ops(int k) { return (k >= 4 && k < 8) ? 2 : (k >= 12 && k < 16) ? 2 : 0; }
+// LDS operations that may still be in flight when the MFMA of gap 8 + j takes Q-row fragment j, read in gap 4 + j / 2:
+// all those of the gaps after that one (the order inside a gap is the compiler's, so none of its own gap is counted)
 __device__ constexpr int g_qa_wait(int j) {
     int n = 0;
-    for (int k = j / 2 + 1; k < 8 + j; ++k) n += g_lds_ops(k);
+    for (int k = 4 + j / 2 + 1; k < 8 + j; ++k) n += g_lds_ops(k);
     return n > 15 ? 15 : n;
 }
 
@@ -75,7 +72,8 @@ __device__ __forceinline__ void g_mfma_x(f32x16& x) {
 }
 
 // Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i or + 4 i; lds_dst in M0).  As asm so that the compiler
-// does not count them; completion is waited for by hand.  M0 is not restored: nothing else in this kernel uses it.
+// does not count them; completion is waited for by hand.
+// M0 is not restored: nothing else in this kernel uses it.
 __device__ __forceinline__ void g_dma16(a4_u32x4 rs, int voff, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                  :: "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
@@ -93,16 +91,8 @@ __device__ __forceinline__ void g_get(float* o) {
 
 }  // namespace
 
-// Timing probes (wrong results): a build with -DG_PROBE=<bits> leaves out one class of the loop's work
-#ifndef G_PROBE
-#define G_PROBE 0
-#endif
-#define G_OPAQUE(x) asm volatile("" : "=v"(x))
-#define G_PIN(x) asm volatile("" : "+v"(x))
-
 template <bool CAUSAL, bool ACCUM_F32>
 __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
-    constexpr int PROBE = G_PROBE;
     constexpr int D = 128;
     constexpr int BQ = 32;             // query rows per unit
     constexpr int KS = D / 16;         // 8
@@ -110,8 +100,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     constexpr int ROWB = D * 2;
     constexpr int CPR = D / 8;
     constexpr int QTILE = BQ * ROWB;   // 8 KiB: a unit's Q (or dO) rows
-    constexpr int SLOTB = 2 * QTILE + 256;   // [Q rows][dO rows][32 x -lse2, 32 x -delta, f32]
-    constexpr int NBUF = 6;            // ring slots: units u-1 .. u+4 at the start of iteration u, which requests u+5
+    constexpr int SLOTB = 2 * QTILE + 256;   // [Q rows][dO rows][32 lse, 32 delta f32]
+    constexpr int NBUF = 6;            // ring slots: units u-? .. u+5 around iteration u
     constexpr int AHEAD = NBUF - 1;    // staging distance in units
     constexpr int HALF = 3;            // slots per address register set (ds offsets are 16-bit)
     constexpr int RPP = 64 / CPR;      // rows per 1-KiB piece: 4
@@ -190,19 +180,18 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     const int64_t x_step_head = x_hs * 2;
     const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
     // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31; ONE request per unit for the
-    // whole workgroup, made by wave (unit number mod 4)
+    // whole workgroup, made by wave (unit number mod 4): a direct-to-LDS request costs its wave far more issue time
+    // than an ordinary load, so it is not duplicated
     const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
     const int64_t c_step_head = p.lse_stride;
     const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
-    // the request of one unit, piece by piece so that they can sit in different gaps; the descriptor is made a gap
-    // before the first piece (a scalar register written by a vector instruction needs five wait states before a memory
-    // instruction reads it, and nothing pads an asm statement) and kept in scalar registers
+    // the request of one unit, in three parts so that they can sit in different gaps: the descriptor is made a gap
+    // before the pieces (a scalar register written by a vector instruction needs five wait states before a memory
+    // instruction reads it, and nothing pads an asm statement)
     a4_u32x4 ld_rs;
-    bool ld_partial = true;
-    const uint32_t ld_dst = lds_base + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
     auto dma_prepare = [&]() __attribute__((always_inline)) {
-        ld_partial = (ld_sl == nslice - 1);
-        const int rows_valid = ld_partial ? rows_last : BQ;
+        const bool partial = (ld_sl == nslice - 1);
+        const int rows_valid = partial ? rows_last : BQ;
         // word by word and said to be wave-uniform (left to itself the compiler does the 64-bit pointer arithmetic of
         // the request stream in vector registers, which a buffer instruction cannot take)
         const uint64_t xb = (uint64_t)(uintptr_t)ld_x;
@@ -212,12 +201,15 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         ld_rs[3] = 0x00020000u;
         asm volatile("" : "+s"(ld_rs));      // made here, not next to its first use
     };
-    auto dma_piece = [&](auto J_, int slot) __attribute__((always_inline)) {
-        constexpr int j = decltype(J_)::value;
-        g_dma16(ld_rs, ld_partial ? voff_part[j] : voff_full[j], ld_dst + slot * SLOTB + j * 1024);
+    auto dma_pieces = [&](int slot) __attribute__((always_inline)) {
+        const bool partial = (ld_sl == nslice - 1);
+        const uint32_t dst = lds_base + slot * SLOTB + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) g_dma16(ld_rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
     };
     auto dma_consts_and_advance = [&](int slot) __attribute__((always_inline)) {
-        if ((ld_n & 3) == w) g_dma4(ld_c + (ld_partial ? c_part : 0), lds_base + slot * SLOTB + 2 * QTILE);
+        const bool partial = (ld_sl == nslice - 1);
+        if ((ld_n & 3) == w) g_dma4(ld_c + (partial ? c_part : 0), lds_base + slot * SLOTB + 2 * QTILE);
         // past the last unit the stream stays where it is: the loop's unconditional requests re-fetch that unit (into
         // slots nobody reads any more)
         const bool adv = (++ld_n < niter);
@@ -228,13 +220,6 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         ld_hg = adv ? (wrap ? 0 : ld_hg + 1) : ld_hg;
         ld_sl = (adv && wrap) ? ld_sl - 1 : ld_sl;
     };
-    // The staged row constants are lse (natural log) and delta.  What the loop wants is -lse * log2(e) (so that P is one
-    // fused multiply-add and one exponential per score) and -delta (the initial accumulator of the dP product, so that dS
-    // is one multiply): the wave that requested a unit's constants rewrites them in place, one float per lane, two
-    // iterations before their first reader (a barrier lies between).
-    const float resc_mul = (lane < 32) ? -1.4426950408889634f : -1.f;
-    lds_char* const resc_ptr = lds0 + 2 * QTILE + 4 * lane;
-    int it_n = 0;         // iterations started so far = number of the current unit
 
     // ---- LDS read addresses: one register set for slots 0..2 and one for slots 3..5 (ds offsets are 16-bit); the slot and
     // the operand (Q at +0, dO at +QTILE, constants at +2 QTILE) are immediates.  Row reads: the XOR swizzle acts on address
@@ -252,29 +237,34 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             t_ptr[0][mt][jh] = lds0 + lds_off128(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
             t_ptr[1][mt][jh] = t_ptr[0][mt][jh] + HALF * SLOTB;
         }
-    lds_char* c_ptr[2];              // row constants of rows 8 g + 4 h .. + 3: -lse2 at +0, -delta at +128
+    lds_char* c_ptr[2];              // row constants of rows 8 g + 4 h .. + 3: lse at +0, delta at +128
     c_ptr[0] = lds0 + 2 * QTILE + 16 * h;
     c_ptr[1] = c_ptr[0] + HALF * SLOTB;
 
     const float c = p.scale_log2e;
 
     // pipeline state carried from one iteration to the next (the dO rows of the current unit are in a[224:255])
-    f32x16 sv0, sv1;      // S of the current unit in one (by the parity of the unit number), of the next in the other
+    f32x16 sv;            // S of the current unit until gap 7, of the next one from gap 8
     f32x16 dp;            // -delta of the current unit's rows at the start of an iteration: the dP product accumulates onto it
     f32x4 l4[4];          // the current unit's -lse * log2(e), rows 8 g + 4 h .. + 3
 
+    // The staged row constants are lse (natural log) and delta.  What the loop wants is -lse * log2(e) (so that P is one
+    // fused multiply-add and one exponential per score) and -delta (the initial accumulator of the dP product, so that dS
+    // is one multiply): the wave that requested a unit's constants rewrites them in place, one float per lane, two
+    // iterations before their first reader (a barrier lies between).
+    const float resc_mul = (lane < 32) ? -1.4426950408889634f : -1.f;
+    lds_char* const resc_ptr = lds0 + 2 * QTILE + 4 * lane;
+    int it_n = 0;         // iterations started so far = number of the current unit
+
     int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
 
-    // One iteration.  SLOT = u mod 6 fixes every ring slot, and with it the register block of S, at compile time.
+    // One iteration.  SLOT = u mod 6 fixes every ring slot at compile time.
     auto iteration = [&](auto SLOT_) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(SLOT_)::value, PAR = SLOT & 1;
+        constexpr int SLOT = decltype(SLOT_)::value;
         constexpr int NEXT = (SLOT + 1) % NBUF;
         constexpr int DMAS = (SLOT + AHEAD) % NBUF;
-        constexpr int RS = (SLOT + 2) % NBUF;         // slot of unit u+2, whose constants wave (u+2) mod 4 rescales now
         constexpr int CS = SLOT / HALF, CO = (SLOT % HALF) * SLOTB;      // address set and byte offset of the current slot
         constexpr int NS = NEXT / HALF, NO = (NEXT % HALF) * SLOTB;      // ... of the next unit's slot
-        f32x16& cur = PAR ? sv1 : sv0;
-        f32x16& nxt = PAR ? sv0 : sv1;
 
         const int i0 = c_sl * BQ;   // first query row of the unit, relative to q_row0
         if (++c_hg == p.group) { c_hg = 0; --c_sl; }
@@ -283,55 +273,23 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         // Everything older than the last two iterations' requests has landed (this wave's share of unit u+2); the
         // barrier makes that true of every wave's share, and tells this wave that all waves are done with the slot of
         // unit u-1, which this iteration's requests overwrite.  No LDS read is left in flight either (the dO rows and
-        // the constants of this unit were read in the last iteration).
-        if constexpr (PROBE & 128) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if constexpr (PROBE & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
+        // the lse of this unit were read at the end of the last iteration).
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 
+        bf16x8 doT[2 * MT], qT[2 * MT];   // transposed fragments (s2, mt) of this unit, each alive for about four gaps
+        float pv[16];
+        constexpr int RS = (SLOT + 2) % NBUF;         // slot of unit u+2, whose constants wave (u+2) mod 4 rescales now
         const bool resc_mine = ((it_n + 2) & 3) == w;
         ++it_n;
         float resc_val = 0.f;
-        bf16x8 doT[2 * MT], qT[2 * MT];   // transposed fragments (s2, mt) of this unit, each alive for about four gaps
-        a4_u32x4 pf[2], dsf[2];           // P and dS of rows 16 s2 .. + 15 as bf16 pairs
+        bf16x8 pf[2], dsf[2];
 
         auto tr_read = [&](bf16x8& f, int set, int off, int mt) __attribute__((always_inline)) {
-            if constexpr (PROBE & 16) { G_OPAQUE(f); return; }
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[set][mt][0] + off));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[set][mt][1] + off));
             f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
             f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        };
-        // P of score i, in place
-        auto expo = [&](int i) __attribute__((always_inline)) {
-            if constexpr (PROBE & 32) return;
-            if constexpr (PROBE & 1) cur[i] = __builtin_fmaf(cur[i], c, l4[i >> 2][i & 3]);
-            else cur[i] = fast_exp2(__builtin_fmaf(cur[i], c, l4[i >> 2][i & 3]));
-            G_PIN(cur[i]);
-        };
-        // the (rare) mask of scores I0 .. I0 + 7; a branch, not selects, which would run for every unit
-        auto mask8 = [&](int I0) __attribute__((always_inline)) {
-            if (need_mask) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int i = I0 + e;
-                    const int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
-                    cur[i] = dead ? 0.f : cur[i];
-                    G_PIN(cur[i]);
-                }
-            }
-        };
-        auto pack = [&](a4_u32x4& dst, int i) __attribute__((always_inline)) {   // scores i, i + 1 -> their dword
-            if constexpr (PROBE & 32) { G_OPAQUE(dst[(i & 7) >> 1]); return; }
-            uint32_t pw = a4_pack(cur[i], cur[i + 1]);
-            G_PIN(pw);
-            dst[(i & 7) >> 1] = pw;
-        };
-        auto dsmul = [&](int i) __attribute__((always_inline)) {
-            if constexpr (PROBE & 32) return;
-            cur[i] = cur[i] * dp[i];
-            G_PIN(cur[i]);
         };
 
         g_static_for<0, 32>([&](auto K_) __attribute__((always_inline)) {
@@ -340,27 +298,24 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             if constexpr (k < 8) {
                 g_mfma_x<g_OA(k), g_VF(k), false, -1>(dp);       // onto -delta
             } else if constexpr (k < 16) {
-                g_mfma_x<g_QA(k - 8), g_KF(k - 8), k == 8, g_qa_wait(k - 8)>(nxt);
+                g_mfma_x<g_QA(k - 8), g_KF(k - 8), k == 8, g_qa_wait(k - 8)>(sv);
             } else if constexpr (k < 24) {
                 constexpr int j = k - 16, s2 = j / MT, mt = j % MT;
-                a4_mfma_o<g_DV(mt), -1>(doT[j], __builtin_bit_cast(bf16x8, pf[s2]));
+                a4_mfma_o<g_DV(mt), -1>(doT[j], pf[s2]);
             } else {
                 constexpr int j = k - 24, s2 = j / MT, mt = j % MT;
-                a4_mfma_o<g_DK(mt), -1>(qT[j], __builtin_bit_cast(bf16x8, dsf[s2]));
+                a4_mfma_o<g_DK(mt), -1>(qT[j], dsf[s2]);
             }
             __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its gap's fillers behind it
 
-            // ---- LDS reads into the accumulator half (g_lds_ops has the count per gap)
-            if constexpr (k < 4 && !(PROBE & 8)) {               // Q rows of unit u+1 -> a[192:223], for gaps 8-15
-                a4_read_k<g_QA(2 * k), NO>(a_addr[NS] ^ (uint32_t)((2 * k) << 5));
-                a4_read_k<g_QA(2 * k + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * k + 1) << 5));
+            // ---- LDS reads, each about four gaps (128 cycles) ahead of its use: the LDS counter holds 15 requests, and a
+            // wave that has more in flight stalls at the next one
+            if constexpr (k >= 4 && k < 8) {        // Q rows of unit u+1 -> a[192:223], two fragments per gap, for gaps 8-15
+                a4_read_k<g_QA(2 * (k - 4)), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4)) << 5));
+                a4_read_k<g_QA(2 * (k - 4) + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4) + 1) << 5));
             }
-            if constexpr (k >= 8 && k < 12 && !(PROBE & 8)) {    // dO rows of unit u+1 -> a[224:255] (this unit's were last read in gap 7)
-                a4_read_k<g_OA(2 * (k - 8)), NO + QTILE>(a_addr[NS] ^ (uint32_t)((2 * (k - 8)) << 5));
-                a4_read_k<g_OA(2 * (k - 8) + 1), NO + QTILE>(a_addr[NS] ^ (uint32_t)((2 * (k - 8) + 1) << 5));
-            }
-            // ---- the compiler's LDS traffic: transposed fragments four gaps ahead of their use, then the constants of
-            // unit u+1; the wave whose turn it is rescales the constants of unit u+2
+            if constexpr (k == 0) { if (resc_mine) resc_val = *(LDS_PTR(float, resc_ptr + RS * SLOTB)); }
+            if constexpr (k == 3) { if (resc_mine) *(LDS_PTR(float, resc_ptr + RS * SLOTB)) = resc_val * resc_mul; }
             if constexpr (k >= 12 && k < 20) {      // dO^T of unit u, fragment k - 12, needed in gap 16 + (k - 12)
                 constexpr int j = k - 12, s2 = j / MT, mt = j % MT;
                 tr_read(doT[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
@@ -369,50 +324,72 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 constexpr int j = k - 20, s2 = j / MT, mt = j % MT;
                 tr_read(qT[j], CS, CO + 16 * s2 * ROWB, mt);
             }
-            if constexpr (k == 4 && !(PROBE & 64)) { if (resc_mine) resc_val = *(LDS_PTR(float, resc_ptr + RS * SLOTB)); }
-            if constexpr (k == 7 && !(PROBE & 64)) { if (resc_mine) *(LDS_PTR(float, resc_ptr + RS * SLOTB)) = resc_val * resc_mul; }
-            if constexpr (k >= 28 && !(PROBE & 64)) {   // -lse2 and -delta of unit u+1 (this unit's were last read in gaps 13 and 21)
-                l4[k - 28] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 28)));
+            if constexpr (k >= 16 && k < 24) {      // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
+                a4_read_k<g_OA(k - 16), NO + QTILE>(a_addr[NS] ^ (uint32_t)((k - 16) << 5));
+            }
+            if constexpr (k >= 24 && k < 28) {      // -lse2 of unit u+1 (this unit's was last read in gap 7)
+                l4[k - 24] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 24)));
+            }
+            if constexpr (k >= 28) {                // -delta of unit u+1: where its dP product starts (dP of this unit was last read in gap 19)
                 const f32x4 t4 = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 128 + 32 * (k - 28)));
                 dp[4 * (k - 28)] = t4[0]; dp[4 * (k - 28) + 1] = t4[1]; dp[4 * (k - 28) + 2] = t4[2]; dp[4 * (k - 28) + 3] = t4[3];
             }
-            // ---- staging requests of unit u+5 (its slot held unit u-1, which every wave finished before this
-            // iteration's barrier), one piece every eighth gap; the constants' request comes last
-            if constexpr (k == 1 && !(PROBE & 4)) dma_prepare();
-            if constexpr ((k & 7) == 2 && !(PROBE & 4)) dma_piece(std::integral_constant<int, k / 8>{}, DMAS);
-            if constexpr (k == 30 && !(PROBE & 4)) dma_consts_and_advance(DMAS);
 
-            // ---- P(u), in place of S(u): scores 0-3 in gaps 0-3, 4-7 in gaps 4-5, 8-15 in gaps 6-13
-            if constexpr (k < 4) expo(k);
-            if constexpr (k == 4 || k == 5) { expo(2 * k - 4); expo(2 * k - 3); }
-            if constexpr (k >= 6 && k < 14) expo(k + 2);
-            // packed for the dV product of gaps 16-19 (rows 0-15) and 20-23 (rows 16-31)
-            if constexpr (k == 6) mask8(0);
-            if constexpr (k >= 6 && k < 10) pack(pf[0], 2 * (k - 6));
-            if constexpr (k == 14) mask8(8);
-            if constexpr (k >= 14 && k < 18) pack(pf[1], 8 + 2 * (k - 14));
-            // ---- dS(u) = P (dP - delta) (the product started from -delta and is complete after gap 7): rows 0-15 in
-            // gaps 10-17 behind their packing, rows 16-31 in gaps 18-21; packed for the dK product of gaps 24-27 / 28-31
-            if constexpr (k >= 10 && k < 18) dsmul(k - 10);
-            if constexpr (k >= 18 && k < 22) { dsmul(8 + 2 * (k - 18)); dsmul(9 + 2 * (k - 18)); }
-            if constexpr (k >= 18 && k < 22) pack(dsf[0], 2 * (k - 18));
-            if constexpr (k >= 22 && k < 26) pack(dsf[1], 8 + 2 * (k - 22));
+            // ---- P(u): two scores per gap in gaps 0-7, the (rare) mask in gap 8, packed in gaps 8-11
+            if constexpr (k < 8) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * k + e;
+                    pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, l4[i >> 2][i & 3]));
+                }
+            }
+            if constexpr (k == 8) {
+                if (need_mask) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
+                        pv[i] = dead ? 0.f : pv[i];
+                        asm volatile("" : "+v"(pv[i]));   // keeps this a branch: as selects it would run for every unit
+                    }
+                }
+            }
+            if constexpr (k >= 8 && k < 12) {
+                constexpr int i = 4 * (k - 8);
+                pf[i >> 3][(i & 7)] = (__bf16)pv[i]; pf[i >> 3][(i & 7) + 1] = (__bf16)pv[i + 1];
+                pf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; pf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
+                if constexpr (k == 9 || k == 11) asm volatile("" : "+v"(pf[(k - 8) >> 1]));   // formed here, not next to its use
+            }
+            // ---- dS(u) = P (dP - delta): two values per gap in gaps 12-19 (the product started from -delta and is complete
+            // after gap 7), packed in 20-23
+            if constexpr (k >= 12 && k < 20) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * (k - 12) + e;
+                    pv[i] = pv[i] * dp[i];
+                }
+            }
+            if constexpr (k >= 20 && k < 24) {
+                constexpr int i = 4 * (k - 20);
+                dsf[i >> 3][(i & 7)] = (__bf16)pv[i]; dsf[i >> 3][(i & 7) + 1] = (__bf16)pv[i + 1];
+                dsf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; dsf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
+                if constexpr (k == 21 || k == 23) asm volatile("" : "+v"(dsf[(k - 20) >> 1]));
+            }
+            // ---- staging requests of unit u+5 (its slot held unit u-1, which every wave finished before this
+            // iteration's barrier)
+            if constexpr (k == 23) dma_prepare();
+            if constexpr (k == 24) dma_pieces(DMAS);
+            if constexpr (k == 28) dma_consts_and_advance(DMAS);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
 
     if (niter > 0) {
-        // prologue: units 0 .. 4 requested and landed, the constants of units 0 and 1 rescaled (iteration 0 takes over
-        // from unit 2); S(0), then the dO rows and the constants of unit 0
+        // prologue: units 0 .. 4 requested and landed; S(0), then the dO rows and the lse of unit 0
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) {
-            dma_prepare();
-            a4_nop<4>();
-            g_static_for<0, PPW>([&](auto J_) __attribute__((always_inline)) { dma_piece(J_, i); });
-            dma_consts_and_advance(i);
-        }
+        for (int i = 0; i < AHEAD; ++i) { dma_prepare(); a4_nop<4>(); dma_pieces(i); dma_consts_and_advance(i); }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (w < 2) {
+        if (w < 2) {       // constants of units 0 and 1 (iteration 0 takes over from unit 2)
             const float t = *(LDS_PTR(float, resc_ptr + w * SLOTB));
             *(LDS_PTR(float, resc_ptr + w * SLOTB)) = t * resc_mul;
         }
@@ -432,7 +409,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
         g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) {
             constexpr int ks = decltype(I_)::value;
-            g_mfma_x<g_QA(ks), g_KF(ks), ks == 0, -1>(sv0);
+            g_mfma_x<g_QA(ks), g_KF(ks), ks == 0, -1>(sv);
         });
         a4_nop<12>();
         __builtin_amdgcn_sched_barrier(0);

@@ -50,10 +50,11 @@ extern "C" int lvattn_select_bwd_kernels(const char* dq, const char* dkdv) {
         if (strcmp(dq, "lockstep")) return fail(LV_EINVAL, "unknown dQ kernel '%s' (default, pp, lockstep)", dq);
         a = 1;
     }
-    if (dkdv && dkdv[0] && strcmp(dkdv, "default") && strcmp(dkdv, "rs")) {
+    if (dkdv && dkdv[0] && strcmp(dkdv, "default")) {
         if (!strcmp(dkdv, "single")) b = 1;
         else if (!strcmp(dkdv, "g")) b = 2;
-        else if (!strcmp(dkdv, "rs1")) units = 1;
+        else if (!strcmp(dkdv, "rs")) b = 3;
+        else if (!strcmp(dkdv, "rs1")) b = 3, units = 1;
         else return fail(LV_EINVAL, "unknown dK/dV kernel '%s' (default, rs, rs1, single, g)", dkdv);
     }
     lv_select_bwd_kernels(a, b);

@@ -269,7 +269,7 @@ def test_forward_extreme_score_ranges(forced_forward_kernel):
             assert (err <= lse_bound(ref_lse)).all(), (D, causal, err.max())   # fp32 log-sum-exp of scores in the thousands
 
 
-@pytest.mark.parametrize("dq_kernel,dkdv_kernel", [("default", "default"), ("lockstep", "single"), ("pp", "rs1"), ("pp", "g")])
+@pytest.mark.parametrize("dq_kernel,dkdv_kernel", [("default", "default"), ("lockstep", "single"), ("pp", "rs"), ("pp", "rs1"), ("pp", "g")])
 def test_backward_hard_score_ranges(dq_kernel, dkdv_kernel):
     """The backward kernels recompute P from the saved log-sum-exp: scores that climb along the keys with a spike (rows
     dominated by one late key), moderately large scores (sharp but not one-hot rows) and all-zero queries (uniform rows),
