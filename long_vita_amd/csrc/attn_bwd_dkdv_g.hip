@@ -13,10 +13,13 @@
 // exponentials, dS, bf16 packing, the LDS fragment reads of later gaps, the staging requests -- and a scheduling
 // barrier after every gap keeps the compiler from packing the MFMAs together and the vector work behind them.
 // Software pipeline of iteration u:
-//   gaps  0- 7  dP(u)    = dO(u) V^T          | P(u) = exp2(c S(u) - lse2(u))   | read Q(u+1) rows, delta(u), dO^T(u)
-//   gaps  8-15  S(u+1)   = Q(u+1) K^T         | pack P(u); dS(u) = P (dP - delta)| read dO^T(u), Q^T(u)
-//   gaps 16-23  dV^T    += dO^T(u) P(u)       | dS(u), pack                      | read Q^T(u), dO(u+1) rows
-//   gaps 24-31  dK^T    += Q^T(u) dS(u)       | staging requests of unit u+5     | read dO(u+1) rows, lse2(u+1)
+//   gaps  0- 7  dP(u)    = dO(u) V^T (onto -delta) | P(u) = exp2(c S(u) - lse2(u))   | read Q(u+1) rows (4-7)
+//   gaps  8-15  S(u+1)   = Q(u+1) K^T              | pack P(u); dS(u) = P dP (12-19) | read dO^T(u) (from 12)
+//   gaps 16-23  dV^T    += dO^T(u) P(u)            | dS(u), pack                     | read dO^T(u), Q^T(u), dO(u+1) rows
+//   gaps 24-31  dK^T    += Q^T(u) dS(u)            | staging requests of unit u+5    | read Q^T(u), -lse2(u+1), -delta(u+1)
+// The staged row constants are lse (natural log) and delta; the wave that requested a unit's constants rewrites them in
+// LDS as -lse * log2(e) and -delta two iterations before their first reader, so that P is one fused multiply-add and one
+// exponential per score, and dS one multiply (the dP product starts from -delta instead of zero).
 // The loop is unrolled over the six ring slots, so every LDS address is a lane register plus an immediate.
 //
 // Register file, laid out by hand as in the one-wave forward kernel (attn_fwd_a4.hip): the accumulator half holds
@@ -74,6 +77,9 @@ __device__ __forceinline__ void g_mfma_x(f32x16& x) {
 // Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i or + 4 i; lds_dst in M0).  As asm so that the compiler
 // does not count them; completion is waited for by hand.
 // M0 is not restored: nothing else in this kernel uses it.
+#ifndef G_PROBE
+#define G_PROBE 0
+#endif
 __device__ __forceinline__ void g_dma16(a4_u32x4 rs, int voff, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                  :: "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
@@ -91,8 +97,12 @@ __device__ __forceinline__ void g_get(float* o) {
 
 }  // namespace
 
+// Timing probes (wrong results): a build with -DG_PROBE=<bits> leaves out one class of the loop's work
+#define G_OPAQUE(x) asm volatile("" : "=v"(x))
+
 template <bool CAUSAL, bool ACCUM_F32>
 __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
+    constexpr int PROBE = G_PROBE;
     constexpr int D = 128;
     constexpr int BQ = 32;             // query rows per unit
     constexpr int KS = D / 16;         // 8
@@ -274,7 +284,9 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         // barrier makes that true of every wave's share, and tells this wave that all waves are done with the slot of
         // unit u-1, which this iteration's requests overwrite.  No LDS read is left in flight either (the dO rows and
         // the lse of this unit were read at the end of the last iteration).
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
+        if constexpr (PROBE & 128) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (PROBE & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 
         bf16x8 doT[2 * MT], qT[2 * MT];   // transposed fragments (s2, mt) of this unit, each alive for about four gaps
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         bf16x8 pf[2], dsf[2];
 
         auto tr_read = [&](bf16x8& f, int set, int off, int mt) __attribute__((always_inline)) {
+            if constexpr (PROBE & 16) { G_OPAQUE(f); return; }
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[set][mt][0] + off));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, t_ptr[set][mt][1] + off));
             f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
@@ -310,12 +323,12 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 
             // ---- LDS reads, each about four gaps (128 cycles) ahead of its use: the LDS counter holds 15 requests, and a
             // wave that has more in flight stalls at the next one
-            if constexpr (k >= 4 && k < 8) {        // Q rows of unit u+1 -> a[192:223], two fragments per gap, for gaps 8-15
+            if constexpr (k >= 4 && k < 8 && !(PROBE & 8)) {        // Q rows of unit u+1 -> a[192:223], two fragments per gap, for gaps 8-15
                 a4_read_k<g_QA(2 * (k - 4)), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4)) << 5));
                 a4_read_k<g_QA(2 * (k - 4) + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4) + 1) << 5));
             }
-            if constexpr (k == 0) { if (resc_mine) resc_val = *(LDS_PTR(float, resc_ptr + RS * SLOTB)); }
-            if constexpr (k == 3) { if (resc_mine) *(LDS_PTR(float, resc_ptr + RS * SLOTB)) = resc_val * resc_mul; }
+            if constexpr (k == 0 && !(PROBE & 64)) { if (resc_mine) resc_val = *(LDS_PTR(float, resc_ptr + RS * SLOTB)); }
+            if constexpr (k == 3 && !(PROBE & 64)) { if (resc_mine) *(LDS_PTR(float, resc_ptr + RS * SLOTB)) = resc_val * resc_mul; }
             if constexpr (k >= 12 && k < 20) {      // dO^T of unit u, fragment k - 12, needed in gap 16 + (k - 12)
                 constexpr int j = k - 12, s2 = j / MT, mt = j % MT;
                 tr_read(doT[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
@@ -324,13 +337,13 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 constexpr int j = k - 20, s2 = j / MT, mt = j % MT;
                 tr_read(qT[j], CS, CO + 16 * s2 * ROWB, mt);
             }
-            if constexpr (k >= 16 && k < 24) {      // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
+            if constexpr (k >= 16 && k < 24 && !(PROBE & 8)) {      // dO rows of unit u+1 -> a[224:255] (read by the dP product of gaps 0-7, long done)
                 a4_read_k<g_OA(k - 16), NO + QTILE>(a_addr[NS] ^ (uint32_t)((k - 16) << 5));
             }
-            if constexpr (k >= 24 && k < 28) {      // -lse2 of unit u+1 (this unit's was last read in gap 7)
+            if constexpr (k >= 24 && k < 28 && !(PROBE & 64)) {      // -lse2 of unit u+1 (this unit's was last read in gap 7)
                 l4[k - 24] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 24)));
             }
-            if constexpr (k >= 28) {                // -delta of unit u+1: where its dP product starts (dP of this unit was last read in gap 19)
+            if constexpr (k >= 28 && !(PROBE & 64)) {                // -delta of unit u+1: where its dP product starts (dP of this unit was last read in gap 19)
                 const f32x4 t4 = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 128 + 32 * (k - 28)));
                 dp[4 * (k - 28)] = t4[0]; dp[4 * (k - 28) + 1] = t4[1]; dp[4 * (k - 28) + 2] = t4[2]; dp[4 * (k - 28) + 3] = t4[3];
             }
@@ -340,7 +353,9 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 2 * k + e;
-                    pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, l4[i >> 2][i & 3]));
+                    if constexpr (PROBE & 32) G_OPAQUE(pv[i]);
+                    else if constexpr (PROBE & 1) pv[i] = __builtin_fmaf(sv[i], c, l4[i >> 2][i & 3]);
+                    else pv[i] = fast_exp2(__builtin_fmaf(sv[i], c, l4[i >> 2][i & 3]));
                 }
             }
             if constexpr (k == 8) {
@@ -354,7 +369,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                     }
                 }
             }
-            if constexpr (k >= 8 && k < 12) {
+            if constexpr (k >= 8 && k < 12 && (PROBE & 32)) { if constexpr (k & 1) G_OPAQUE(pf[(k - 8) >> 1]); }
+            if constexpr (k >= 8 && k < 12 && !(PROBE & 32)) {
                 constexpr int i = 4 * (k - 8);
                 pf[i >> 3][(i & 7)] = (__bf16)pv[i]; pf[i >> 3][(i & 7) + 1] = (__bf16)pv[i + 1];
                 pf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; pf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
@@ -362,14 +378,15 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             }
             // ---- dS(u) = P (dP - delta): two values per gap in gaps 12-19 (the product started from -delta and is complete
             // after gap 7), packed in 20-23
-            if constexpr (k >= 12 && k < 20) {
+            if constexpr (k >= 12 && k < 20 && !(PROBE & 32)) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 2 * (k - 12) + e;
                     pv[i] = pv[i] * dp[i];
                 }
             }
-            if constexpr (k >= 20 && k < 24) {
+            if constexpr (k >= 20 && k < 24 && (PROBE & 32)) { if constexpr (k & 1) G_OPAQUE(dsf[(k - 20) >> 1]); }
+            if constexpr (k >= 20 && k < 24 && !(PROBE & 32)) {
                 constexpr int i = 4 * (k - 20);
                 dsf[i >> 3][(i & 7)] = (__bf16)pv[i]; dsf[i >> 3][(i & 7) + 1] = (__bf16)pv[i + 1];
                 dsf[i >> 3][(i & 7) + 2] = (__bf16)pv[i + 2]; dsf[i >> 3][(i & 7) + 3] = (__bf16)pv[i + 3];
@@ -377,9 +394,9 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             }
             // ---- staging requests of unit u+5 (its slot held unit u-1, which every wave finished before this
             // iteration's barrier)
-            if constexpr (k == 23) dma_prepare();
-            if constexpr (k == 24) dma_pieces(DMAS);
-            if constexpr (k == 28) dma_consts_and_advance(DMAS);
+            if constexpr (k == 23 && !(PROBE & 4)) dma_prepare();
+            if constexpr (k == 24 && !(PROBE & 4)) dma_pieces(DMAS);
+            if constexpr (k == 28 && !(PROBE & 4)) dma_consts_and_advance(DMAS);
             __builtin_amdgcn_sched_barrier(0);
         });
     };

@@ -3,7 +3,7 @@
 # (timing only; a probe build computes wrong gradients).  Every object is rebuilt: a stale one must never be linked.
 set -e
 cd "$(dirname "$0")/../long_vita_amd/csrc"
-rm -f build/g_probe_*.o ../liblvattn_gp*.so
+rm -f build/g_probe_*.o ../liblvattn_gp*.so   # (bits: 1 exponentials, 2 barrier, 4 staging requests, 8 row reads, 16 transposed reads, 32 vector arithmetic, 64 row constants, 128 the counted vmcnt wait)
 make -j8 >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -fno-slp-vectorize -Wno-uninitialized"
 OTHERS=$(ls build/*.o | grep -v attn_bwd_dkdv_g.o | grep -v g_probe_)
