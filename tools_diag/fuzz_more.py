@@ -10,8 +10,8 @@ from tests.test_gpu_fuzz import _case, _rel
 
 first, n = int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 200
 L = _lib.lib()
-variants = [(b"default", b"default", b"default"), (b"pp", b"pp", b"rs1"), (b"lockstep", b"lockstep", b"single"), (b"pp16", b"default", b"default"),
-            (b"a4", b"default", b"default")]
+variants = [(b"default", b"default", b"default"), (b"pp", b"pp", b"rs1"), (b"lockstep", b"lockstep", b"single"), (b"pp16", b"default", b"rs"),
+            (b"a4", b"default", b"g")]
 bad = 0
 t0 = time.time()
 for seed in range(first, first + n):
