@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     };
     auto dma_consts_and_advance = [&](int slot) __attribute__((always_inline)) {
         const bool partial = (ld_sl == nslice - 1);
-        if ((ld_n & 3) == w) g_dma4(ld_c + (partial ? c_part : 0), lds_base + slot * SLOTB + 2 * QTILE);
+        if ((ld_n & 3) == w && !(G_PROBE & 256)) g_dma4(ld_c + (partial ? c_part : 0), lds_base + slot * SLOTB + 2 * QTILE);
         // past the last unit the stream stays where it is: the loop's unconditional requests re-fetch that unit (into
         // slots nobody reads any more)
         const bool adv = (++ld_n < niter);
