@@ -184,15 +184,24 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         voff_full[j] = row * (int)(x_rs * 2) + ch16;
         voff_part[j] = min(row, rows_last - 1) * (int)(x_rs * 2) + ch16;   // rows past the end repeat the last valid one
     }
-    const int c_part = min(r, rows_last - 1) - r;
-    int ld_sl = nslice - 1, ld_hg = 0, ld_n = 0;   // (slice, head) of the next request; requests so far
-    const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)ld_sl * BQ * x_rs);
+    // The request stream: (slice, head) of the next unit to request, walked with as few scalar instructions as it takes (a
+    // lone wave pays four cycles for each).  Only the first slice requested (the last of the sweep) can be partial: its
+    // offsets and record count are the stream's initial state and are replaced when the stream leaves that slice.  Past
+    // the last unit the stream keeps walking, with zero records: nothing is fetched, the slot is one nobody reads.
+    int voff_cur[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) voff_cur[j] = voff_part[j];
+    int c_cur = min(r, rows_last - 1) - r;      // the constants' row of this lane, relative to row r of the slice
+    const int rec_full = (BQ - 1) * (int)(x_rs * 2) + ROWB;
+    int rec_cur = (rows_last - 1) * (int)(x_rs * 2) + ROWB;
+    int ld_hg = 0, ld_n = 0;                    // head of the next request inside its group; requests so far
+    const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)(nslice - 1) * BQ * x_rs);
     const int64_t x_step_head = x_hs * 2;
     const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
     // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31; ONE request per unit for the
     // whole workgroup, made by wave (unit number mod 4): a direct-to-LDS request costs its wave far more issue time
     // than an ordinary load, so it is not duplicated
-    const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)ld_sl * BQ + r;
+    const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)(nslice - 1) * BQ + r;
     const int64_t c_step_head = p.lse_stride;
     const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
     // the request of one unit, in three parts so that they can sit in different gaps: the descriptor is made a gap
@@ -200,35 +209,35 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     // instruction reads it, and nothing pads an asm statement)
     a4_u32x4 ld_rs;
     auto dma_prepare = [&]() __attribute__((always_inline)) {
-        const bool partial = (ld_sl == nslice - 1);
-        const int rows_valid = partial ? rows_last : BQ;
         // word by word and said to be wave-uniform (left to itself the compiler does the 64-bit pointer arithmetic of
         // the request stream in vector registers, which a buffer instruction cannot take)
         const uint64_t xb = (uint64_t)(uintptr_t)ld_x;
         ld_rs[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb);
         ld_rs[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xb >> 32)) & 0xffffu;
-        ld_rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((rows_valid - 1) * (int)(x_rs * 2) + ROWB));
+        ld_rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane(ld_n < niter ? rec_cur : 0);
         ld_rs[3] = 0x00020000u;
         asm volatile("" : "+s"(ld_rs));      // made here, not next to its first use
     };
     auto dma_pieces = [&](int slot) __attribute__((always_inline)) {
-        const bool partial = (ld_sl == nslice - 1);
         const uint32_t dst = lds_base + slot * SLOTB + (w_is_do ? QTILE : 0) + PPW * (w & 1) * 1024;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) g_dma16(ld_rs, partial ? voff_part[j] : voff_full[j], dst + j * 1024);
+        for (int j = 0; j < PPW; ++j) g_dma16(ld_rs, voff_cur[j], dst + j * 1024);
     };
     auto dma_consts_and_advance = [&](int slot) __attribute__((always_inline)) {
-        const bool partial = (ld_sl == nslice - 1);
-        if ((ld_n & 3) == w && !(G_PROBE & 256)) g_dma4(ld_c + (partial ? c_part : 0), lds_base + slot * SLOTB + 2 * QTILE);
-        // past the last unit the stream stays where it is: the loop's unconditional requests re-fetch that unit (into
-        // slots nobody reads any more)
-        const bool adv = (++ld_n < niter);
-        const bool wrap = (ld_hg + 1 == p.group);
-        const int64_t xs = wrap ? x_step_slice : x_step_head, cs = wrap ? c_step_slice : c_step_head;
-        ld_x += adv ? xs : 0;
-        ld_c += adv ? cs : 0;
-        ld_hg = adv ? (wrap ? 0 : ld_hg + 1) : ld_hg;
-        ld_sl = (adv && wrap) ? ld_sl - 1 : ld_sl;
+        if ((ld_n & 3) == w && ld_n < niter && !(G_PROBE & 256)) g_dma4(ld_c + c_cur, lds_base + slot * SLOTB + 2 * QTILE);
+        ++ld_n;
+        if (++ld_hg == p.group) {       // on to the slice before
+            ld_hg = 0;
+            ld_x += x_step_slice;
+            ld_c += c_step_slice;
+            rec_cur = rec_full;
+            c_cur = 0;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) voff_cur[j] = voff_full[j];
+        } else {
+            ld_x += x_step_head;
+            ld_c += c_step_head;
+        }
     };
 
     // ---- LDS read addresses: one register set for slots 0..2 and one for slots 3..5 (ds offsets are 16-bit); the slot and
@@ -267,6 +276,10 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     int it_n = 0;         // iterations started so far = number of the current unit
 
     int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
+    // A unit needs the mask when its first row i0 is below the wave's last key's diagonal (kbase_w + 31 > i0 + shift), when
+    // its rows run past the segment (i0 + BQ > q_len), or always when the wave's keys run past the key block.
+    const int mask_below = (kbase_w + 32 > k_rows) ? 0x7fffffff : kbase_w + 31 - shift;
+    const int mask_from = q_len - BQ + 1;
 
     // One iteration.  SLOT = u mod 6 fixes every ring slot at compile time.
     auto iteration = [&](auto SLOT_) __attribute__((always_inline)) {
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 
         const int i0 = c_sl * BQ;   // first query row of the unit, relative to q_row0
         if (++c_hg == p.group) { c_hg = 0; --c_sl; }
-        const bool need_mask = (kbase_w + 31 > i0 + shift) || (i0 + BQ > q_len) || (kbase_w + 32 > k_rows);
+        const bool need_mask = (i0 < mask_below) || (i0 >= mask_from);
 
         // Everything older than the last two iterations' requests has landed (this wave's share of unit u+2); the
         // barrier makes that true of every wave's share, and tells this wave that all waves are done with the slot of
