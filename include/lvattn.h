@@ -237,7 +237,8 @@ int lvattn_decode_noalloc(const void* q, const void* k, const void* v, void* out
  *           dK/dV: one work item per key block    (descriptors from lv_build_bwd_blocks*)
  *           dQ   : one work item per query block  (descriptors from lv_build_fwd_blocks*)
  *         With accum_f32 == 0, dq [rows,hq,d] / dk / dv [rows,hkv,d] are bf16 and written;
- *         with accum_f32 != 0 they are fp32 buffers that are ADDED to (ring steps).
+ *         with accum_f32 == 1 they are fp32 buffers that are ADDED to (ring steps); with accum_f32 == 2
+ *         fp32 buffers that are written (the partial results of split sweeps: no zero fill, no read).
  *         Strides of dq/dk/dv are in elements of their own type. */
 int lvattn_bwd_delta(const void* out, const void* dout, float* delta,
                      int rows, int hq, int d,

@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_kernel(BwdParams p) {
                 if constexpr (ACCUM_F32) {
                     float* dkp = reinterpret_cast<float*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
                     float* dvp = reinterpret_cast<float*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
-                    f32x4 a = *reinterpret_cast<f32x4*>(dkp), b = *reinterpret_cast<f32x4*>(dvp);
+                    f32x4 a = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dkp);
+                    f32x4 b = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dvp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] += dk[mt][4 * g4 + e] * p.scale; b[e] += dv[mt][4 * g4 + e]; }
                     *reinterpret_cast<f32x4*>(dkp) = a;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void lv_bwd_dq_kernel(BwdParams p) {
                 const int dcol = 32 * mt + 8 * g4 + 4 * h;
                 if constexpr (ACCUM_F32) {
                     float* dqp = reinterpret_cast<float*>(p.dq) + grow * p.dq_rs + (int64_t)head * p.dq_hs + dcol;
-                    f32x4 a = *reinterpret_cast<f32x4*>(dqp);
+                    f32x4 a = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dqp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] += dq[mt][4 * g4 + e] * p.scale;
                     *reinterpret_cast<f32x4*>(dqp) = a;

@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 if constexpr (ACCUM_F32) {
                     float* dkp = reinterpret_cast<float*>(p.dk) + grow * p.dk_rs + (int64_t)kvh * p.dk_hs + dcol;
                     float* dvp = reinterpret_cast<float*>(p.dv) + grow * p.dv_rs + (int64_t)kvh * p.dv_hs + dcol;
-                    f32x4 a = *reinterpret_cast<f32x4*>(dkp), b = *reinterpret_cast<f32x4*>(dvp);
+                    f32x4 a = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dkp);
+                    f32x4 b = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dvp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] += dkk[mt][4 * g4 + e] * p.scale; b[e] += dvv[mt][4 * g4 + e]; }
                     *reinterpret_cast<f32x4*>(dkp) = a;

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dkdv_rs_kernel(BwdParams p) {
                 const int dcol = 32 * mt + 8 * g4 + 4 * h;
                 if constexpr (ACCUM_F32) {
                     float* gp = reinterpret_cast<float*>(gbase) + grow * g_rs + (int64_t)kvh * g_hs + dcol;
-                    f32x4 a = *reinterpret_cast<f32x4*>(gp);
+                    f32x4 a = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(gp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] += acc[mt][4 * g4 + e] * f;
                     *reinterpret_cast<f32x4*>(gp) = a;

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void lv_bwd_dq_pp_kernel(BwdParams p) {
                 const int dcol = 32 * mt + 8 * g4 + 4 * h;
                 if constexpr (ACCUM_F32) {
                     float* dqp = reinterpret_cast<float*>(p.dq) + grow * p.dq_rs + (int64_t)head * p.dq_hs + dcol;
-                    f32x4 a = *reinterpret_cast<f32x4*>(dqp);
+                    f32x4 a = p.f32_store ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(dqp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] += dq[mt][4 * g4 + e] * p.scale;
                     *reinterpret_cast<f32x4*>(dqp) = a;

@@ -504,7 +504,9 @@ extern "C" int lvattn_bwd(const void* q, const void* k, const void* v, const voi
     p.do_rs = do_rs; p.do_hs = do_hs; p.dq_rs = dq_rs; p.dq_hs = dq_hs;
     p.dk_rs = dk_rs; p.dk_hs = dk_hs; p.dv_rs = dv_rs; p.dv_hs = dv_hs;
     p.lse_stride = lse_stride; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
-    if (lv_launch_bwd(p, d, causal, accum_f32, (hipStream_t)stream))
+    if (accum_f32 < 0 || accum_f32 > 2) return fail(LV_EINVAL, "accum_f32 = %d (0 bf16 results, 1 fp32 added to, 2 fp32 stored)", accum_f32);
+    p.f32_store = (accum_f32 == 2);
+    if (lv_launch_bwd(p, d, causal, accum_f32 != 0, (hipStream_t)stream))
         return fail(LV_ELAUNCH, "backward launch failed: %s", hipGetErrorString(hipGetLastError()));
     return LV_OK;
 }

@@ -90,6 +90,7 @@ struct BwdParams {
     int q_rows_total, k_rows_total;
     int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs, dq_rs, dq_hs, dk_rs, dk_hs, dv_rs, dv_hs, lse_stride;
     float scale, scale_log2e;
+    int f32_store;   // fp32 results are stored, not added to what the buffers hold (accum_f32 == 2)
 };
 int lv_launch_bwd(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);
 int lv_launch_bwd_dkdv_rs(const BwdParams& p, int d, int causal, int accum, hipStream_t stream);  // role-split dK/dV kernel

@@ -273,10 +273,10 @@ def decode_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
 
 
 def attn_bwd_launch(q, k, v, out, dout, lse, desc_q: torch.Tensor, desc_k: torch.Tensor, scale: float, causal: bool,
-                    dq=None, dk=None, dv=None, delta=None, accum_f32: bool = False):
+                    dq=None, dk=None, dv=None, delta=None, accum_f32: bool | int = False):
     """Backward of ``attn_fwd_launch``.  ``desc_q`` are the forward's query-block descriptors
     (dQ kernel), ``desc_k`` the key-block descriptors (dK/dV kernel).  Returns (dq, dk, dv, delta):
-    bf16 tensors that are written or, with ``accum_f32``, fp32 buffers that are added to.
+    bf16 tensors that are written or, with ``accum_f32``, fp32 buffers that are added to (True / 1) or written (2).
     Rows no descriptor covers are left untouched (buffers allocated here start at zero)."""
     q, k, v, dout, out = (_last_contig(t) for t in (q, k, v, dout, out))
     _check_qkv(q, k, v)
@@ -476,17 +476,27 @@ def attn_fwd_split_launch(q, k, v, tables: SplitTables, scale: float, causal: bo
     return out, lse
 
 
+_poison_workspaces = False     # test hook: fill the split path's fp32 workspaces with NaN, so that a row read without having been written shows
+
+
+def _workspace(shape, dev):
+    if _poison_workspaces:
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
 def attn_bwd_split_launch(q, k, v, out, dout, lse, tq: SplitTables, tk: SplitTables, scale: float, causal: bool,
                           covered: bool = False):
-    """Backward through split tables: fp32 partials of dq (forward-form table) and dk / dv (key-block table) in zeroed
-    workspaces, summed per block in a fixed order.  Returns bf16 (dq, dk, dv)."""
+    """Backward through split tables: fp32 partials of dq (forward-form table) and dk / dv (key-block table) stored to
+    workspace rows of their own, summed per block in a fixed order.  Returns bf16 (dq, dk, dv)."""
     rq, hq, d = q.shape
     rk, hkv, _ = k.shape
     dev = q.device
-    dq_ws = torch.zeros((tq.ws_rows, hq, d), dtype=torch.float32, device=dev)
-    dk_ws = torch.zeros((tk.ws_rows, hkv, d), dtype=torch.float32, device=dev)
-    dv_ws = torch.zeros((tk.ws_rows, hkv, d), dtype=torch.float32, device=dev)
-    attn_bwd_launch(q, k, v, out, dout, lse, tq.desc, tk.desc, scale, causal, dq_ws, dk_ws, dv_ws, accum_f32=True)
+    # (every work item writes all the rows of its piece, and the combine reads no others: no zero fill)
+    dq_ws = _workspace((tq.ws_rows, hq, d), dev)
+    dk_ws = _workspace((tk.ws_rows, hkv, d), dev)
+    dv_ws = _workspace((tk.ws_rows, hkv, d), dev)
+    attn_bwd_launch(q, k, v, out, dout, lse, tq.desc, tk.desc, scale, causal, dq_ws, dk_ws, dv_ws, accum_f32=2)
     make = torch.empty if covered else torch.zeros       # rows no segment covers get a zero gradient
     dq = make((rq, hq, d), dtype=torch.bfloat16, device=dev)
     dk = make((rk, hkv, d), dtype=torch.bfloat16, device=dev)
