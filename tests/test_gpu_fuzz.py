@@ -88,3 +88,43 @@ def test_random_packing_forward_one_wave_kernel(seed):
     tag = f"Hq={Hq} Hkv={Hkv} causal={causal} cu={cu}"
     assert _rel(out, ref_o) <= REL_TOL, tag
     assert np.abs(lse.detach().cpu().numpy().astype(np.float64) - ref_lse).max() <= LSE_TOL, tag
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_band_or_split_forward_backward(seed):
+    """The same random packings through the other two table forms: a band of random width (causal cases), or the sweeps
+    cut at random forced piece lengths with the fp32 workspaces pre-filled with NaN."""
+    from long_vita_amd import ops
+    D, Hkv, Hq, causal, cu = _case(seed)
+    rs = np.random.RandomState(7000 + seed)
+    banded = causal and rs.rand() < 0.5
+    T = cu[-1]
+    g = torch.Generator().manual_seed(9000 + seed)
+    q = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(T, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(T, Hkv, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    band = int(rs.choice([0, 1, 5, 31, 32, 33, 63, 64, 100, 255, 256, 257, 500])) if banded else None
+    pieces = (int(rs.choice([0, 256, 320, 512, 1024])), int(rs.choice([0, 32, 96, 128, 256, 512])))
+    ref_o, ref_lse = A.varlen_attention(q, k, v, cu, scale, causal, band)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale, causal, band)
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    ops._poison_workspaces = True
+    if not banded:
+        ops.set_split_override(*pieces)
+    try:
+        out, lse = ops.varlen_attention(qc, kc, vc, cu, scale, causal, band)
+        out.backward(do.cuda())
+        torch.cuda.synchronize()
+    finally:
+        ops.set_split_override(None, None)
+        ops._poison_workspaces = False
+    tag = f"D={D} Hq={Hq} Hkv={Hkv} causal={causal} band={band} pieces={pieces} cu={cu}"
+    assert _rel(out, ref_o) <= REL_TOL, tag
+    fin = np.isfinite(ref_lse)
+    if fin.any():
+        assert np.abs(lse.detach().cpu().numpy().astype(np.float64)[fin] - ref_lse[fin]).max() <= LSE_TOL, tag
+    for got, ref, name in ((qc.grad, rdq, "dq"), (kc.grad, rdk, "dk"), (vc.grad, rdv, "dv")):
+        assert torch.isfinite(got.float()).all(), (name, tag)
+        assert _rel(got, ref) <= REL_TOL, (name, tag)
