@@ -633,8 +633,8 @@ static bool dq_pingpong() {
 }
 
 // dK/dV kernel choice.  Left to the library: the gap-scheduled one-wave kernel (attn_bwd_dkdv_g.hip) at head dim 128
-// (same-box A/B, 131,072 tokens, forward + backward: one segment 630.0 -> 618.3 ms, packed segments 72.3 -> 71.0 ms, packed
-// at 5 / 1 heads 9.81 -> 9.70 ms), the role-split kernel (attn_bwd_dkdv_rs.hip) at head dim 64 and for descriptors with a
+// (same-box A/B, 131,072 tokens, forward + backward: one segment 642.5 -> 619.5 ms, packed segments 73.4 -> 71.1 ms, packed
+// at 5 / 1 heads 10.00 -> 9.62 ms), the role-split kernel (attn_bwd_dkdv_rs.hip) at head dim 64 and for descriptors with a
 // band.  The environment variable LVATTN_DKDV_KERNEL = rs / g / single forces one.
 static int dkdv_choice() {   // 0 the library's choice, 1 the first-generation kernel in this file, 2 gap-scheduled (d = 128), 3 role-split
     if (g_dkdv_kernel < 0) {
@@ -656,7 +656,8 @@ static void launch_d(const BwdParams& p, int causal, int accum, hipStream_t stre
     causal = causal != 0;
     if (p.n_blocks > 0 && banded) {
         lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);
-    } else if (p.n_blocks > 0 && (dkdv_choice() == 2 || dkdv_choice() == 0) && D == 128) {
+    } else if (p.n_blocks > 0 && (dkdv_choice() == 2 || dkdv_choice() == 0) && D == 128 && (int64_t)p.hq * p.lse_stride * 4 <= 0xffffffffLL) {
+        // (that kernel addresses the [hq, lse_stride] row constants with 32-bit byte offsets)
         lv_launch_bwd_dkdv_g(p, causal, accum, stream);
     } else if (p.n_blocks > 0 && dkdv_choice() != 1) {
         lv_launch_bwd_dkdv_rs(p, D, causal, accum, stream);

@@ -17,10 +17,12 @@
 //   gaps  8-15  S(u+1)   = Q(u+1) K^T              | pack P(u); dS(u) = P dP (12-19) | read dO^T(u) (from 12)
 //   gaps 16-23  dV^T    += dO^T(u) P(u)            | dS(u), pack                     | read dO^T(u), Q^T(u), dO(u+1) rows
 //   gaps 24-31  dK^T    += Q^T(u) dS(u)            | staging requests of unit u+5    | read Q^T(u), -lse2(u+1), -delta(u+1)
-// The staged row constants are lse (natural log) and delta; the wave that requested a unit's constants rewrites them in
-// LDS as -lse * log2(e) and -delta two iterations before their first reader, so that P is one fused multiply-add and one
-// exponential per score, and dS one multiply (the dP product starts from -delta instead of zero).
-// The loop is unrolled over the six ring slots, so every LDS address is a lane register plus an immediate.
+// The row constants (lse, natural log, and delta) come one loop trip -- six units -- per pair of requests into a small
+// ring of their own; the wave that requested a block rewrites it in LDS as -lse * log2(e) and -delta before its first
+// reader, so that P is one fused multiply-add and one exponential per score, and dS one multiply (the dP product starts
+// from -delta instead of zero).
+// The loop is unrolled over the six ring slots, so every LDS address is a lane register plus an immediate, and so is
+// every decision about the constants (whose request it is, which iteration rescales, where a unit's constants lie).
 //
 // Register file, laid out by hand as in the one-wave forward kernel (attn_fwd_a4.hip): the accumulator half holds
 //   a[0:63] dV^T (tile mt at 16 mt)   a[64:127] dK^T   a[128:159] K fragments   a[160:191] V fragments
@@ -74,7 +76,7 @@ __device__ __forceinline__ void g_mfma_x(f32x16& x) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(x) : "i"(A), "i"(A + 3), "i"(B), "i"(B + 3));
 }
 
-// Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i or + 4 i; lds_dst in M0).  As asm so that the compiler
+// Direct global -> LDS loads (lane i -> LDS byte lds_dst + 16 i; lds_dst in M0).  As asm so that the compiler
 // does not count them; completion is waited for by hand.
 // M0 is not restored: nothing else in this kernel uses it.
 #ifndef G_PROBE
@@ -84,11 +86,6 @@ __device__ __forceinline__ void g_dma16(a4_u32x4 rs, int voff, uint32_t lds_dst)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                  :: "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void g_dma4(const float* g, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                 :: "v"(g), "s"(lds_dst) : "memory");
-}
-
 template <int A, int N>
 __device__ __forceinline__ void g_get(float* o) {
     o[0] = a4_get<A>();
@@ -110,7 +107,10 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     constexpr int ROWB = D * 2;
     constexpr int CPR = D / 8;
     constexpr int QTILE = BQ * ROWB;   // 8 KiB: a unit's Q (or dO) rows
-    constexpr int SLOTB = 2 * QTILE + 256;   // [Q rows][dO rows][32 lse, 32 delta f32]
+    constexpr int SLOTB = 2 * QTILE;   // [Q rows][dO rows]
+    constexpr int CBLKB = 2048;        // row constants of the six units of one loop trip: [6][32] x -lse2 at +0, [6][32] x -delta at +1024 (f32)
+    constexpr int NCB = 3;             // ring of such blocks: the trip's, the next trip's, the one on its way
+    constexpr int CST0 = 6 * SLOTB;    // ... behind the unit slots
     constexpr int NBUF = 6;            // ring slots: units u-? .. u+5 around iteration u
     constexpr int AHEAD = NBUF - 1;    // staging distance in units
     constexpr int HALF = 3;            // slots per address register set (ds offsets are 16-bit)
@@ -191,19 +191,42 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     int voff_cur[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) voff_cur[j] = voff_part[j];
-    int c_cur = min(r, rows_last - 1) - r;      // the constants' row of this lane, relative to row r of the slice
     const int rec_full = (BQ - 1) * (int)(x_rs * 2) + ROWB;
     int rec_cur = (rows_last - 1) * (int)(x_rs * 2) + ROWB;
     int ld_hg = 0, ld_n = 0;                    // head of the next request inside its group; requests so far
     const char* ld_x = reinterpret_cast<const char*>(x_base + (int64_t)kvh * p.group * x_hs + (int64_t)(nslice - 1) * BQ * x_rs);
     const int64_t x_step_head = x_hs * 2;
     const int64_t x_step_slice = -((int64_t)(p.group - 1) * x_hs + (int64_t)BQ * x_rs) * 2;
-    // row constants: lanes 0..31 fetch lse of rows 0..31, lanes 32..63 delta of rows 0..31; ONE request per unit for the
-    // whole workgroup, made by wave (unit number mod 4): a direct-to-LDS request costs its wave far more issue time
-    // than an ordinary load, so it is not duplicated
-    const float* ld_c = ((lane < 32) ? p.lse : p.delta) + q_row0 + (int64_t)kvh * p.group * p.lse_stride + (int64_t)(nslice - 1) * BQ + r;
-    const int64_t c_step_head = p.lse_stride;
-    const int64_t c_step_slice = -((int64_t)(p.group - 1) * p.lse_stride + BQ);
+    // Row constants (lse and delta of a unit's 32 rows) come one loop trip -- six units -- at a time: a direct-to-LDS
+    // request costs the wave that issues it about sixty cycles whatever it carries, and the other three waves then
+    // wait for it at the barrier (one 256-byte request per unit was 4.5 % of the kernel).  Two 1-KiB requests, one per
+    // array, bring a trip's constants: lane = 8 (unit in the trip) + (group of four rows), 16 bytes each, lanes 48..63
+    // repeat the last unit into padding.  The whole [hq, lse_stride] arrays are the buffers: a group of rows past the
+    // end of a segment reads whatever lies there (those rows are masked, and their dP sanitised, below), one past the
+    // end of the array reads zero.  Block b is requested by wave b mod 4 two trips ahead, in the trip's first
+    // iteration, so whose turn it is and where a unit's constants lie are compile-time facts of the unrolled loop.
+    a4_u32x4 rs_lse, rs_delta;
+    {
+        const uint32_t nrec = (uint32_t)((int64_t)p.hq * p.lse_stride * 4);   // < 2^32: the launcher checks
+        const uint64_t lb = (uint64_t)(uintptr_t)p.lse, db = (uint64_t)(uintptr_t)p.delta;
+        rs_lse[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lb);
+        rs_lse[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lb >> 32)) & 0xffffu;
+        rs_lse[2] = nrec; rs_lse[3] = 0x00020000u;
+        rs_delta[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)db);
+        rs_delta[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(db >> 32)) & 0xffffu;
+        rs_delta[2] = nrec; rs_delta[3] = 0x00020000u;
+    }
+    const int64_t c_row0 = (int64_t)kvh * p.group * p.lse_stride + q_row0 + 4 * (lane & 7);   // + head * lse_stride + 32 * slice
+    const int c_unit = (lane >> 3) < 6 ? (lane >> 3) : 5;
+    auto dma_const_block = [&](int blk, int cslot) __attribute__((always_inline)) {
+        int n = blk * 6 + c_unit;
+        n = n < niter ? n : niter - 1;        // past the last unit: the last one again
+        const int sl_back = n / p.group, hg = n - sl_back * p.group;
+        const int voff = (int)((c_row0 + (int64_t)hg * p.lse_stride + (int64_t)(nslice - 1 - sl_back) * BQ) * 4);
+        const uint32_t dst = lds_base + CST0 + cslot * CBLKB;
+        g_dma16(rs_lse, voff, dst);
+        g_dma16(rs_delta, voff, dst + CBLKB / 2);
+    };
     // the request of one unit, in three parts so that they can sit in different gaps: the descriptor is made a gap
     // before the pieces (a scalar register written by a vector instruction needs five wait states before a memory
     // instruction reads it, and nothing pads an asm statement)
@@ -223,25 +246,21 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) g_dma16(ld_rs, voff_cur[j], dst + j * 1024);
     };
-    auto dma_consts_and_advance = [&](int slot) __attribute__((always_inline)) {
-        if ((ld_n & 3) == w && ld_n < niter && !(G_PROBE & 256)) g_dma4(ld_c + c_cur, lds_base + slot * SLOTB + 2 * QTILE);
+    auto dma_advance = [&]() __attribute__((always_inline)) {
         ++ld_n;
         if (++ld_hg == p.group) {       // on to the slice before
             ld_hg = 0;
             ld_x += x_step_slice;
-            ld_c += c_step_slice;
             rec_cur = rec_full;
-            c_cur = 0;
 #pragma unroll
             for (int j = 0; j < PPW; ++j) voff_cur[j] = voff_full[j];
         } else {
             ld_x += x_step_head;
-            ld_c += c_step_head;
         }
     };
 
     // ---- LDS read addresses: one register set for slots 0..2 and one for slots 3..5 (ds offsets are 16-bit); the slot and
-    // the operand (Q at +0, dO at +QTILE, constants at +2 QTILE) are immediates.  Row reads: the XOR swizzle acts on address
+    // the operand (Q at +0, dO at +QTILE) are immediates.  Row reads: the XOR swizzle acts on address
     // bits 4..7 only and every slot starts on a multiple of 256 bytes, so fragment ks (chunk 2 ks + h) is the address of
     // fragment 0 with ks XORed into bits 5..7.
     uint32_t a_addr[2];
@@ -256,9 +275,12 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             t_ptr[0][mt][jh] = lds0 + lds_off128(8 * jh + 4 * h + q4, 4 * mt + 2 * gl + (p4 >> 1)) + 8 * (p4 & 1);
             t_ptr[1][mt][jh] = t_ptr[0][mt][jh] + HALF * SLOTB;
         }
-    lds_char* c_ptr[2];              // row constants of rows 8 g + 4 h .. + 3: lse at +0, delta at +128
-    c_ptr[0] = lds0 + 2 * QTILE + 16 * h;
-    c_ptr[1] = c_ptr[0] + HALF * SLOTB;
+    // row constants of rows 8 g + 4 h .. + 3 of unit i of a trip: block base + 128 i + 32 g (-lse2), + 1024 more (-delta)
+    lds_char* const c_lane = lds0 + CST0 + 16 * h;
+    lds_char* c_blk = c_lane;                 // this trip's block
+    lds_char* c_blk_next = c_lane + CBLKB;    // the next trip's
+    int c_slot = 0;                           // ring slot of this trip's block; the trip number mod 4 says whose turn a request is
+    int trip_w = 0;
 
     const float c = p.scale_log2e;
 
@@ -269,13 +291,22 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 
     // The staged row constants are lse (natural log) and delta.  What the loop wants is -lse * log2(e) (so that P is one
     // fused multiply-add and one exponential per score) and -delta (the initial accumulator of the dP product, so that dS
-    // is one multiply): the wave that requested a unit's constants rewrites them in place, one float per lane, two
-    // iterations before their first reader (a barrier lies between).
-    const float resc_mul = (lane < 32) ? -1.4426950408889634f : -1.f;
-    lds_char* const resc_ptr = lds0 + 2 * QTILE + 4 * lane;
-    int it_n = 0;         // iterations started so far = number of the current unit
+    // is one multiply): the wave that requested a block rewrites it in place, 16 + 16 bytes per lane, in the third
+    // iteration of the trip before the block's (barriers lie between that and the first reader).
+    lds_char* const resc_ptr = lds0 + CST0 + 16 * lane;
+    auto rescale_load = [&](int cslot, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        a = *(LDS_PTR(f32x4, resc_ptr + cslot * CBLKB));
+        b = *(LDS_PTR(f32x4, resc_ptr + cslot * CBLKB + CBLKB / 2));
+    };
+    auto rescale_store = [&](int cslot, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] *= -1.4426950408889634f; b[e] = -b[e]; }
+        *(LDS_PTR(f32x4, resc_ptr + cslot * CBLKB)) = a;
+        *(LDS_PTR(f32x4, resc_ptr + cslot * CBLKB + CBLKB / 2)) = b;
+    };
 
     int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
+    int trip_n = 0;                    // trips of the unrolled loop done
     // A unit needs the mask when its first row i0 is below the wave's last key's diagonal (kbase_w + 31 > i0 + shift), when
     // its rows run past the segment (i0 + BQ > q_len), or always when the wave's keys run past the key block.
     const int mask_below = (kbase_w + 32 > k_rows) ? 0x7fffffff : kbase_w + 31 - shift;
@@ -297,17 +328,22 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         // barrier makes that true of every wave's share, and tells this wave that all waves are done with the slot of
         // unit u-1, which this iteration's requests overwrite.  No LDS read is left in flight either (the dO rows and
         // the lse of this unit were read at the end of the last iteration).
+        // (the wave that requested a block of constants in the trip's first iteration has those two requests in flight
+        // in the next two: counting them in keeps the wait from reaching into the last two iterations' pieces)
+        const bool creq_mine = (((trip_w + 2) & 3) == w);       // this trip's request is this wave's
         if constexpr (PROBE & 128) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if constexpr (PROBE & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+        else if ((SLOT == 1 || SLOT == 2) && creq_mine) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW + 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_sched_barrier(0);
 
         bf16x8 doT[2 * MT], qT[2 * MT];   // transposed fragments (s2, mt) of this unit, each alive for about four gaps
         float pv[16];
-        constexpr int RS = (SLOT + 2) % NBUF;         // slot of unit u+2, whose constants wave (u+2) mod 4 rescales now
-        const bool resc_mine = ((it_n + 2) & 3) == w;
-        ++it_n;
-        float resc_val = 0.f;
+        // constants: the trip's first iteration requests the block two trips on, its third rescales the next trip's
+        const bool resc_mine = (((trip_w + 1) & 3) == w);
+        const int c_slot1 = (c_slot == NCB - 1) ? 0 : c_slot + 1, c_slot2 = (c_slot1 == NCB - 1) ? 0 : c_slot1 + 1;
+        f32x4 resc_a, resc_b;
+        lds_char* const c_rd = (SLOT == NBUF - 1 ? c_blk_next : c_blk) + ((SLOT + 1) % NBUF) * (BQ * 4);   // unit u+1's constants
         bf16x8 pf[2], dsf[2];
 
         auto tr_read = [&](bf16x8& f, int set, int off, int mt) __attribute__((always_inline)) {
@@ -340,8 +376,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 a4_read_k<g_QA(2 * (k - 4)), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4)) << 5));
                 a4_read_k<g_QA(2 * (k - 4) + 1), NO>(a_addr[NS] ^ (uint32_t)((2 * (k - 4) + 1) << 5));
             }
-            if constexpr (k == 0 && !(PROBE & 64)) { if (resc_mine) resc_val = *(LDS_PTR(float, resc_ptr + RS * SLOTB)); }
-            if constexpr (k == 3 && !(PROBE & 64)) { if (resc_mine) *(LDS_PTR(float, resc_ptr + RS * SLOTB)) = resc_val * resc_mul; }
+            if constexpr (SLOT == 2 && k == 0 && !(PROBE & 64)) { if (resc_mine) rescale_load(c_slot1, resc_a, resc_b); }
+            if constexpr (SLOT == 2 && k == 3 && !(PROBE & 64)) { if (resc_mine) rescale_store(c_slot1, resc_a, resc_b); }
             if constexpr (k >= 12 && k < 20) {      // dO^T of unit u, fragment k - 12, needed in gap 16 + (k - 12)
                 constexpr int j = k - 12, s2 = j / MT, mt = j % MT;
                 tr_read(doT[j], CS, CO + QTILE + 16 * s2 * ROWB, mt);
@@ -354,10 +390,10 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                 a4_read_k<g_OA(k - 16), NO + QTILE>(a_addr[NS] ^ (uint32_t)((k - 16) << 5));
             }
             if constexpr (k >= 24 && k < 28 && !(PROBE & 64)) {      // -lse2 of unit u+1 (this unit's was last read in gap 7)
-                l4[k - 24] = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 32 * (k - 24)));
+                l4[k - 24] = *(LDS_PTR(f32x4, c_rd + 32 * (k - 24)));
             }
             if constexpr (k >= 28 && !(PROBE & 64)) {                // -delta of unit u+1: where its dP product starts (dP of this unit was last read in gap 19)
-                const f32x4 t4 = *(LDS_PTR(f32x4, c_ptr[NS] + NO + 128 + 32 * (k - 28)));
+                const f32x4 t4 = *(LDS_PTR(f32x4, c_rd + CBLKB / 2 + 32 * (k - 28)));
                 dp[4 * (k - 28)] = t4[0]; dp[4 * (k - 28) + 1] = t4[1]; dp[4 * (k - 28) + 2] = t4[2]; dp[4 * (k - 28) + 3] = t4[3];
             }
 
@@ -379,6 +415,17 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
                         const bool dead = (kj > ii + shift) | (ii >= q_len) | (kj >= k_rows);
                         pv[i] = dead ? 0.f : pv[i];
                         asm volatile("" : "+v"(pv[i]));   // keeps this a branch: as selects it would run for every unit
+                    }
+                    // a row past the end of the segment read whatever lay behind the segment's constants: its dP product
+                    // started from anything, NaN included (the product's last MFMA is a gap old: wait its result out)
+                    if (i0 >= mask_from) {
+                        a4_nop<16>(); a4_nop<16>();
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ii = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            dp[i] = (ii >= q_len) ? 0.f : dp[i];
+                            asm volatile("" : "+v"(dp[i]));
+                        }
                     }
                 }
             }
@@ -409,7 +456,17 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             // iteration's barrier)
             if constexpr (k == 23 && !(PROBE & 4)) dma_prepare();
             if constexpr (k == 24 && !(PROBE & 4)) dma_pieces(DMAS);
-            if constexpr (k == 28 && !(PROBE & 4)) dma_consts_and_advance(DMAS);
+            if constexpr (k == 28 && !(PROBE & 4)) {
+                if constexpr (SLOT == 0 && !(PROBE & 256)) { if (creq_mine) dma_const_block(trip_n + 2, c_slot2); }
+                dma_advance();
+            }
+            if constexpr (SLOT == NBUF - 1 && k == 31) {      // on to the next trip
+                ++trip_n;
+                trip_w = (trip_w + 1) & 3;
+                c_slot = c_slot1;
+                c_blk = c_blk_next;
+                c_blk_next = c_lane + c_slot2 * CBLKB;
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -417,11 +474,13 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     if (niter > 0) {
         // prologue: units 0 .. 4 requested and landed; S(0), then the dO rows and the lse of unit 0
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) { dma_prepare(); a4_nop<4>(); dma_pieces(i); dma_consts_and_advance(i); }
+        for (int i = 0; i < AHEAD; ++i) { dma_prepare(); a4_nop<4>(); dma_pieces(i); dma_advance(); }
+        if (w < 2) dma_const_block(w, w);      // the constants of trips 0 and 1 (trip 0 requests those of trip 2)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (w < 2) {       // constants of units 0 and 1 (iteration 0 takes over from unit 2)
-            const float t = *(LDS_PTR(float, resc_ptr + w * SLOTB));
-            *(LDS_PTR(float, resc_ptr + w * SLOTB)) = t * resc_mul;
+        if (w == 0) {      // (trip 1's block is rescaled by the loop, in trip 0's third iteration, like every later one)
+            f32x4 ta, tb;
+            rescale_load(0, ta, tb);
+            rescale_store(0, ta, tb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         g_static_for<0, KS>([&](auto I_) __attribute__((always_inline)) {
@@ -431,8 +490,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         });
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            l4[g] = *(LDS_PTR(f32x4, c_ptr[0] + 32 * g));
-            const f32x4 t4 = *(LDS_PTR(f32x4, c_ptr[0] + 128 + 32 * g));
+            l4[g] = *(LDS_PTR(f32x4, c_lane + 32 * g));
+            const f32x4 t4 = *(LDS_PTR(f32x4, c_lane + CBLKB / 2 + 32 * g));
             dp[4 * g] = t4[0]; dp[4 * g + 1] = t4[1]; dp[4 * g + 2] = t4[2]; dp[4 * g + 3] = t4[3];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -501,7 +560,8 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
 int lv_launch_bwd_dkdv_g(const BwdParams& p, int causal, int accum, hipStream_t stream) {
     if (p.n_blocks <= 0) return 0;
     dim3 grid((unsigned)((((int64_t)p.n_blocks * p.hkv + 7) / 8) * 8)), block(256);
-    const size_t lds = (size_t)6 * (2 * 32 * 128 * 2 + 256);
+    if ((int64_t)p.hq * p.lse_stride * 4 > 0xffffffffLL) return -3;   // the row constants are addressed with 32-bit byte offsets
+    const size_t lds = (size_t)6 * (2 * 32 * 128 * 2) + 3 * 2048;   // unit slots + the constants' ring
     if (causal) {
         if (accum) hipLaunchKernelGGL((lv_bwd_dkdv_g_kernel<true, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((lv_bwd_dkdv_g_kernel<true, false>), grid, block, lds, stream, p);
