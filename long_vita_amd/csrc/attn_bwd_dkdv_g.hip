@@ -217,15 +217,24 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         rs_delta[2] = nrec; rs_delta[3] = 0x00020000u;
     }
     const int64_t c_row0 = (int64_t)kvh * p.group * p.lse_stride + q_row0 + 4 * (lane & 7);   // + head * lse_stride + 32 * slice
-    const int c_unit = (lane >> 3) < 6 ? (lane >> 3) : 5;
-    auto dma_const_block = [&](int blk, int cslot) __attribute__((always_inline)) {
-        int n = blk * 6 + c_unit;
-        n = n < niter ? n : niter - 1;        // past the last unit: the last one again
-        const int sl_back = n / p.group, hg = n - sl_back * p.group;
+    // A wave's blocks are w, w + 4, w + 8, ...: the lane keeps (unit number, slices back from the last one, head in the
+    // group) of its unit of the wave's NEXT block and steps them by 24 units after each request, so that no request
+    // pays for a division.
+    int cn_unit = 6 * w + ((lane >> 3) < 6 ? (lane >> 3) : 5);
+    int cn_sl = cn_unit / p.group, cn_hg = cn_unit - cn_sl * p.group;
+    const int cn_sl24 = 24 / p.group, cn_hg24 = 24 - cn_sl24 * p.group;
+    const int cn_sl_last = (niter - 1) / p.group, cn_hg_last = (niter - 1) - cn_sl_last * p.group;
+    auto dma_const_block = [&](int cslot) __attribute__((always_inline)) {
+        const bool past = cn_unit >= niter;        // past the last unit: the last one again
+        const int sl_back = past ? cn_sl_last : cn_sl, hg = past ? cn_hg_last : cn_hg;
         const int voff = (int)((c_row0 + (int64_t)hg * p.lse_stride + (int64_t)(nslice - 1 - sl_back) * BQ) * 4);
         const uint32_t dst = lds_base + CST0 + cslot * CBLKB;
         g_dma16(rs_lse, voff, dst);
         g_dma16(rs_delta, voff, dst + CBLKB / 2);
+        cn_unit += 24;
+        cn_sl += cn_sl24;
+        cn_hg += cn_hg24;
+        if (cn_hg >= p.group) { cn_hg -= p.group; ++cn_sl; }
     };
     // the request of one unit, in three parts so that they can sit in different gaps: the descriptor is made a gap
     // before the pieces (a scalar register written by a vector instruction needs five wait states before a memory
@@ -306,7 +315,6 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
     };
 
     int c_sl = nslice - 1, c_hg = 0;   // (slice, head) being computed
-    int trip_n = 0;                    // trips of the unrolled loop done
     // A unit needs the mask when its first row i0 is below the wave's last key's diagonal (kbase_w + 31 > i0 + shift), when
     // its rows run past the segment (i0 + BQ > q_len), or always when the wave's keys run past the key block.
     const int mask_below = (kbase_w + 32 > k_rows) ? 0x7fffffff : kbase_w + 31 - shift;
@@ -457,11 +465,10 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
             if constexpr (k == 23 && !(PROBE & 4)) dma_prepare();
             if constexpr (k == 24 && !(PROBE & 4)) dma_pieces(DMAS);
             if constexpr (k == 28 && !(PROBE & 4)) {
-                if constexpr (SLOT == 0 && !(PROBE & 256)) { if (creq_mine) dma_const_block(trip_n + 2, c_slot2); }
+                if constexpr (SLOT == 0 && !(PROBE & 256)) { if (creq_mine) dma_const_block(c_slot2); }   // (any gap does: 2, 12 and 28 measured the same)
                 dma_advance();
             }
             if constexpr (SLOT == NBUF - 1 && k == 31) {      // on to the next trip
-                ++trip_n;
                 trip_w = (trip_w + 1) & 3;
                 c_slot = c_slot1;
                 c_blk = c_blk_next;
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256) void lv_bwd_dkdv_g_kernel(BwdParams p) {
         // prologue: units 0 .. 4 requested and landed; S(0), then the dO rows and the lse of unit 0
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) { dma_prepare(); a4_nop<4>(); dma_pieces(i); dma_advance(); }
-        if (w < 2) dma_const_block(w, w);      // the constants of trips 0 and 1 (trip 0 requests those of trip 2)
+        if (w < 2) dma_const_block(w);         // the constants of trips 0 and 1 (trip 0 requests those of trip 2)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (w == 0) {      // (trip 1's block is rescaled by the loop, in trip 0's third iteration, like every later one)
             f32x4 ta, tb;
