@@ -212,8 +212,9 @@ int lvattn_decode(const void* q, const void* k, const void* v, void* out, float*
  * forbid hipMalloc.  Same arguments and results as lvattn_decode minus the workspace.  Returns LV_ESIZE when
  * batch * hkv * n_split * (hq / hkv) * (d + 1) * 4 bytes exceed the buffer (pass a smaller n_split or use
  * lvattn_decode).  For 40 / 8 heads at d = 128 that is batch * n_split <= 406; the default split keeps
- * batch * hkv * n_split near 512 (n_split = ceil(512 / (batch * hkv)), at least 1), i.e. about 1.3 MiB of partial
- * results, so the default fits at any batch up to 406 and only an explicit large n_split overflows.
+ * batch * hkv * n_split near 512 (768 for caches of 393,216 tokens and more: n_split = ceil(512 or 768 / (batch * hkv)),
+ * at least 1), i.e. at most about 2 MiB of partial results, so the default fits at any batch up to 406 and only an
+ * explicit large n_split overflows.
  * The first call on each GPU looks the buffer's device address up (hipGetSymbolAddress, which may load the code
  * object): make that first call OUTSIDE stream capture; later calls on that GPU are capture-safe.  All calls on one
  * GPU share the buffer: calls that overlap on one GPU (two streams, two threads) race and must be serialised by the
