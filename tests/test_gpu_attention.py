@@ -548,3 +548,40 @@ def test_full_size_backward_invariants_cfg3_packed():
                 got = out.detach()[row, h].double()
                 assert (got - want).abs().max().item() <= REL_TOL * max(want.abs().max().item(), 1e-2), (row, h, n)
                 assert abs(lse[h, row].item() - torch.logsumexp(s_, 0).item()) <= LSE_TOL
+
+
+@pytest.mark.parametrize("dkdv", ["g", "rs"])
+def test_backward_with_padded_row_constants_full_of_nan(dkdv):
+    """lse and delta live in [hq, lse_stride] arrays whose rows are longer than the packed batch (lse_stride > rows); the
+    padding holds NaN here, and so does everything behind a segment's last row that is not another segment's.  The one-wave
+    dK/dV kernel fetches row constants sixteen bytes at a time and so reads past a ragged segment end: what it reads
+    there must not reach dk / dv (segments of 1000 and 41 rows: partial last slices; d = 128, grouped heads)."""
+    from long_vita_amd import ops, _lib
+    cu, Hq, Hkv, D = [0, 1000, 1041], 10, 2, 128
+    T = cu[-1]
+    q, k, v = make_qkv(T, Hq, Hkv, D, seed=77)
+    g = torch.Generator().manual_seed(6)
+    do = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+    scale = A.default_scale(D)
+    rdq, rdk, rdv = A.varlen_attention_grad(q, k, v, do, cu, scale, True)
+    qc, kc, vc, doc = (t.cuda() for t in (q, k, v, do))
+    stride = T + 87
+    lse = torch.full((Hq, stride), float("nan"), dtype=torch.float32, device="cuda")[:, :T]
+    out = torch.empty_like(qc)
+    desc_q = ops.blocks_on_device(cu, True, False, qc.device)
+    desc_k = ops.blocks_on_device(cu, True, True, qc.device)
+    ops.attn_fwd_launch(qc, kc, vc, desc_q, scale, True, out, lse)
+    assert lse.stride(0) == stride
+    delta_buf = torch.full((Hq, stride), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().lvattn_bwd_delta(out.data_ptr(), doc.data_ptr(), delta_buf.data_ptr(), T, Hq, D, out.stride(0), out.stride(1),
+                                          doc.stride(0), doc.stride(1), stride, torch.cuda.current_stream().cuda_stream), "delta")
+    assert torch.isnan(delta_buf[:, T:]).all() and torch.isfinite(delta_buf[:, :T]).all()
+    _lib.check(_lib.lib().lvattn_select_bwd_kernels(b"pp", dkdv.encode()), "select")
+    try:
+        dq, dk, dv, _ = ops.attn_bwd_launch(qc, kc, vc, out, doc, lse, desc_q, desc_k, scale, True, delta=delta_buf)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(_lib.lib().lvattn_select_bwd_kernels(b"default", b"default"), "select")
+    for got, ref, name in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
+        assert torch.isfinite(got.float()).all(), name
+        assert rel_err(got, ref) <= REL_TOL, name
