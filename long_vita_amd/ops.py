@@ -406,17 +406,23 @@ def plan_split(cu_seqlens, causal: bool, hq: int, hkv: int, device):
     """(piece_keys, piece_rows) for the forward / dQ and the dK/dV launch of a packed batch: 0 = leave that launch as it
     is.  The planner simulates a heaviest-first schedule of the launch's work items on the device's compute units and
     cuts the sweeps when the launch has too few items to fill them (lv_plan_fwd_split / lv_plan_bwd_split)."""
-    cu = np.ascontiguousarray(np.asarray(cu_seqlens, dtype=np.int32))
-    n_seg = cu.shape[0] - 1
-    L = _lib.lib()
-    n_cu = _n_cu(device)
     pf = _split_override["fwd"]
     pb = _split_override["bwd"]
-    if pf is None:
-        pf = check(L.lv_plan_fwd_split(cu.ctypes.data_as(_I32P), n_seg, int(causal), hq, n_cu), "lv_plan_fwd_split")
-    if pb is None:
-        pb = check(L.lv_plan_bwd_split(cu.ctypes.data_as(_I32P), n_seg, int(causal), hkv, hq // hkv, n_cu), "lv_plan_bwd_split")
-    return int(pf), int(pb)
+    if pf is not None and pb is not None:
+        return int(pf), int(pb)
+    # (the simulation costs the host 0.05 - 1.3 ms for batches of 3K - 32K tokens, and every layer of a step asks the same
+    # question: the answer is cached like the tables)
+    key = ("plan", tuple(int(x) for x in cu_seqlens), bool(causal), int(hq), int(hkv), str(device))
+
+    def build():
+        cu = np.ascontiguousarray(np.asarray(cu_seqlens, dtype=np.int32))
+        n_seg = cu.shape[0] - 1
+        L = _lib.lib()
+        n_cu = _n_cu(device)
+        return (check(L.lv_plan_fwd_split(cu.ctypes.data_as(_I32P), n_seg, int(causal), hq, n_cu), "lv_plan_fwd_split"),
+                check(L.lv_plan_bwd_split(cu.ctypes.data_as(_I32P), n_seg, int(causal), hkv, hq // hkv, n_cu), "lv_plan_bwd_split"))
+    planned = _blocks.get(key, build)
+    return int(planned[0] if pf is None else pf), int(planned[1] if pb is None else pb)
 
 
 def split_tables_on_device(cu_seqlens, causal: bool, backward: bool, piece: int, device) -> SplitTables:
